@@ -1,0 +1,118 @@
+/* libmavahip.so - C ABI of the MI355X-native PPO hot path (gfx950 only).
+ *
+ * Drop-in boundary: Mava has no FFI; the reusable seam is the Python
+ * learner contract  learn(LearnerState) -> ExperimentOutput  (mava/types.py:146-154,
+ * call site mava/systems/ppo/ff_mappo.py:497).  mava_amd/learner.py keeps that contract and
+ * drives the device work through the entry points below with ctypes.  Every pointer is a
+ * DEVICE pointer (torch.Tensor.data_ptr()) unless marked "host"; buffers are caller-owned,
+ * contiguous, and never retained past the call.  Every function is asynchronous on the given
+ * stream and returns 0 on success, -(hipError_t) for a runtime failure or -1000-k for a
+ * rejected argument; the message is available from mava_last_error().
+ *
+ * Each entry cites the reference code it replaces (paths relative to the Mava repository).
+ */
+#ifndef MAVA_HIP_H
+#define MAVA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mava_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* mava_last_error(void); /* thread-local text of the last failure */
+int mava_abi_version(void);
+
+/* ---- GAE: mava/systems/ppo/ff_mappo.py:112-139 (_calculate_gae);
+ *           mava/systems/ppo/rec_mappo.py:177-199 when last_done != NULL.
+ * reward,value,adv,tgt: (T,N) f32 time-major; done: (T,N) u8; last_val: (N) f32;
+ * last_done: (N) u8 or NULL.  Recurrent mode: done[t] is the flag ENTERING step t and the mask
+ * of step t is done[t+1] (done[T] := last_done). */
+int mava_gae_f32(const float* reward, const float* value, const uint8_t* done,
+                 const float* last_val, const uint8_t* last_done, int T, int N, float gamma,
+                 float lambda, float* adv, float* tgt, mava_stream_t s);
+int mava_gae_set_variant(int variant); /* bench-only tuning knob, 0 = default */
+
+/* ---- optimiser: optax.chain(clip_by_global_norm, adam(eps=1e-5)) per network,
+ *      mava/systems/ppo/ff_mappo.py:359-366 (definition) and :241-250 (application);
+ *      LR schedule mava/utils/training.py:20-64; pmean scaling ff_mappo.py:224-238.
+ * p,g,m,v: flat f32 over all segments (networks); seg_off: host int[n_seg+1]; seg_lr: host
+ * float[n_seg]; count: device int32[n_seg] (incremented).  g holds the SUM over replicas and
+ * ranks; grad_scale = 1/(update_batch_size * n_devices).  loss_sums (device, 3 floats:
+ * actor_loss, entropy, value_loss - same summation) and metrics_out (device, 4 floats:
+ * total_loss, value_loss, actor_loss, entropy; ff_mappo.py:255-265) may both be NULL. */
+int mava_clip_adam(float* p, const float* g, float* m, float* v, int32_t* count,
+                   const int* seg_off, const float* seg_lr, int n_seg, float grad_scale,
+                   float max_norm, int decay, int steps_per_update, int num_updates, float b1,
+                   float b2, float eps, const float* loss_sums, float vf_coef, float ent_coef,
+                   float* metrics_out, mava_stream_t s);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_b slab[b*slab_stride + i], b ascending. */
+int mava_slab_reduce_f32(const float* slab, int n_slab, long slab_stride, int n, int accumulate,
+                         float* out, mava_stream_t s);
+
+/* ---- networks: mava/networks.py:39-58 (MLPTorso [128,128] relu), :88-124
+ *      (DiscreteActionHead), :172-207 (FeedForwardActor / FeedForwardValueNet).
+ * Flat parameter layout [W1(din,128) | b1 | W2(128,128) | b2 | W3(128,n_out) | b3], kernels
+ * row-major (in,out) as in flax.linen.Dense. */
+int mava_mlp_param_count(int din, int n_out);
+
+/* out (rows, n_out) = net(x[row / x_share]);  x: (ceil(rows/x_share), din). */
+int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x, int x_share,
+                         int rows, float* out, mava_stream_t s);
+
+/* One acting step, mava/systems/ppo/ff_mappo.py:80-85: actor forward + action mask
+ * (networks.py:116-120) + Categorical sample / log_prob (distributions.py:146-165), and critic
+ * forward, in one launch.  rows = envs*agents.  agents_view (rows, actor_din);
+ * action_mask (rows, n_actions) u8 or NULL; critic_input (critic_rows/critic_share.., critic_din)
+ * with critic row r reading input row r / critic_share; each critic output is written
+ * value_broadcast times (value index r*value_broadcast + b).  Sampling: Gumbel-max on
+ * Philox4x32-10 keyed by seed with counter (row_offset + row, step, word-group, "POLI").
+ * forced_action (rows) i32 or NULL: score these actions instead of sampling.
+ * logits (rows, n_actions) or NULL: raw (unmasked) logits out. */
+int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
+                         const float* agents_view, const uint8_t* action_mask,
+                         const float* critic_params, int critic_din, const float* critic_input,
+                         int critic_share, int critic_rows, int value_broadcast, int rows,
+                         uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                         const int32_t* forced_action, int32_t* action, float* log_prob,
+                         float* value, float* logits, mava_stream_t s);
+
+/* ---- PPO minibatch gradients: mava/systems/ppo/ff_mappo.py:150-218 (losses + value_and_grad)
+ *      with the shuffle of :268-285 applied as an index vector (no shuffled copy).
+ * The trajectory is the flat time-major batch of TE = T*E env rows with A agent rows each:
+ * every per-agent array is (TE*A, ...).  A minibatch is Rb env rows: idx[b] (int32, a slice of the
+ * epoch permutation) or idx_base + b when idx is NULL.  Each of the n_slab persistent blocks
+ * writes one partial slab of slab_stride floats: [gradient in parameter layout | loss sums];
+ * mava_slab_reduce_f32 sums the slabs in a fixed order.  All sums are already divided by the
+ * minibatch element count Rb*A (the .mean() of the reference). */
+
+int mava_adv_stats_blocks(void); /* number of (sum, sumsq) f64 pairs mava_adv_stats_f64 writes */
+
+/* advantage statistics for ff_mappo.py:164 (mean / population std over the whole minibatch) */
+int mava_adv_stats_f64(const float* advantages, const int32_t* idx, long idx_base, int Rb, int A,
+                       double* partials, mava_stream_t s);
+
+/* _actor_loss_fn, ff_mappo.py:150-180.  slab tail: [actor_loss, entropy]. */
+int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const float* agents_view,
+                            const uint8_t* action_mask, const int32_t* action,
+                            const float* old_log_prob, const float* advantages,
+                            const double* adv_stats, const int32_t* idx, long idx_base, int Rb,
+                            int A, float clip_eps, float ent_coef, float* slab, long slab_stride,
+                            int n_slab, mava_stream_t s);
+
+/* _critic_loss_fn, ff_mappo.py:182-201.  critic_input row = agent_row / x_share.
+ * slab tail: [value_loss, unused]. */
+int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_input, int x_share,
+                             const float* old_value, const float* targets, const int32_t* idx,
+                             long idx_base, int Rb, int A, float clip_eps, float vf_coef,
+                             float* slab, long slab_stride, int n_slab, mava_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAVA_HIP_H */

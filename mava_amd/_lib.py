@@ -1,0 +1,89 @@
+"""ctypes binding of libmavahip.so (include/mava_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or an entry point fails, an
+exception is raised.  torch is imported first so the HIP runtime already resident in the process
+(torch/lib/libamdhip64.so, soname libamdhip64.so.7) is the one the library binds to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (must precede loading libmavahip.so)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmavahip.so")
+
+_lib: Optional[C.CDLL] = None
+
+
+class MavaHipError(RuntimeError):
+    pass
+
+
+vp = C.c_void_p
+i32 = C.c_int
+u32 = C.c_uint32
+u64 = C.c_uint64
+f32 = C.c_float
+lng = C.c_long
+
+# name -> argtypes (all return int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "mava_abi_version": [],
+    "mava_gae_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
+    "mava_gae_set_variant": [i32],
+    "mava_clip_adam": [vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, f32, f32, i32, i32, i32,
+                       f32, f32, f32, vp, f32, f32, vp, vp],
+    "mava_slab_reduce_f32": [vp, i32, lng, i32, i32, vp, vp],
+    "mava_mlp_param_count": [i32, i32],
+    "mava_mlp_forward_f32": [vp, i32, i32, vp, i32, i32, vp, vp],
+    "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, u32, i32,
+                             vp, vp, vp, vp, vp, vp],
+    "mava_adv_stats_blocks": [],
+    "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
+    "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
+                                vp],
+    "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
+}
+_RESTYPES = {"mava_last_error": C.c_char_p}
+
+
+def declared_symbols():
+    """Every symbol include/mava_hip.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(list(_SIGNATURES) + list(_RESTYPES))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MavaHipError(
+                f"{LIB_PATH} is missing: build it with `python -m mava_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mava_last_error.restype = C.c_char_p
+        _lib.mava_last_error.argtypes = []
+        for name, args in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mava_last_error().decode("utf-8", "replace")
+        raise MavaHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

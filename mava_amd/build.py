@@ -1,0 +1,85 @@
+"""In-tree build of libmavahip.so (hipcc, gfx950 only) and of the C oracle.
+
+`python -m mava_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
+Objects are rebuilt only when a source or header is newer than the object.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "csrc")
+OUT_LIB = os.path.join(ROOT, "libmavahip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+HIP_SOURCES = [
+    "gae.hip",
+    "adam.hip",
+    "mlp_policy.hip",
+    "ppo_train.hip",
+    "synth_rware.hip",
+    "engine.hip",
+]
+CPP_SOURCES = ["api.cpp"]
+
+COMMON_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "..", "include")]
+HIP_FLAGS = [f"--offload-arch={ARCH}", "-ffp-contract=fast", "-Wno-unused-result"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "..", "include", "mava_hip.h"))
+    return [h for h in hs if os.path.exists(h)]
+
+
+def _stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src, os.path.abspath(__file__)] + _headers()
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, verbose: bool) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    if not _stale(path, obj):
+        return obj
+    cmd = [HIPCC, "-c", path, "-o", obj] + COMMON_FLAGS
+    if src.endswith(".hip"):
+        cmd += HIP_FLAGS
+    else:
+        cmd += ["-x", "hip", f"--offload-arch={ARCH}"] if False else []
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build(verbose: bool = False, jobs: int = 4) -> str:
+    srcs = [s for s in HIP_SOURCES + CPP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    need_link = (not os.path.exists(OUT_LIB)) or any(
+        os.path.getmtime(o) > os.path.getmtime(OUT_LIB) for o in objs
+    )
+    if need_link:
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT_LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return OUT_LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

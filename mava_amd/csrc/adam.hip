@@ -1,0 +1,192 @@
+// Fused per-network global-norm clip + Adam, in place, one launch (K11 / SURVEY §8 row A10),
+// and the deterministic slab reducer that produces the flat gradient it consumes.
+//
+// Reference wiring: mava/systems/ppo/ff_mappo.py:359-366 builds, per network,
+//   optax.chain(optax.clip_by_global_norm(max_grad_norm), optax.adam(lr, eps=1e-5))
+// and ff_mappo.py:241-250 applies it; the learning rate is constant or the linear schedule of
+// mava/utils/training.py:20-64 evaluated at the optimiser's pre-increment step count.
+// optax is not vendored in the reference; its published semantics are restated here
+// (parity unpinned, see oracle/ppo_oracle.py):
+//   n = sqrt(sum g^2) over the whole network;  g <- g if n < c else (g / n) * c
+//   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; t = count + 1
+//   p <- p - lr(count) * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps) ; count <- t
+//
+// The incoming gradient is the SUM over (update-batch replicas x ranks); grad_scale = 1/(U*D)
+// turns it into the pmean of ff_mappo.py:224-238.
+//
+// MI355X mapping: 77 K parameters = 2.1 MB of traffic, i.e. launch/latency bound.  One launch:
+// every block first reduces the whole (L2-resident) gradient of each network in the same fixed
+// order, so all blocks hold a bit-identical norm with no grid barrier and no atomics, then
+// updates its own slice of p/m/v with 16-byte accesses where alignment allows.
+#include "common.h"
+
+namespace {
+
+constexpr int ADAM_THREADS = 256;
+constexpr int MAX_SEG = 8;
+
+struct AdamSegs {
+  int off[MAX_SEG + 1];
+  float lr[MAX_SEG];
+};
+
+__device__ inline double block_sum(double x, double* sh) {
+  // wave reduce (64 lanes) then across the 4 waves, fixed order
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = x;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < ADAM_THREADS / 64; ++i) t += sh[i];
+  return t;
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void clip_adam_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+    float* __restrict__ v, int32_t* __restrict__ count, AdamSegs segs, int n_seg,
+    float grad_scale, float max_norm, int decay, int steps_per_update, int num_updates, float b1,
+    float b2, float eps, const float* __restrict__ loss_sums, float vf_coef, float ent_coef,
+    float* __restrict__ metrics_out) {
+  __shared__ double sh[ADAM_THREADS / 64];
+  __shared__ float s_clip[MAX_SEG];
+  __shared__ float s_bc1[MAX_SEG], s_bc2[MAX_SEG];  // 1 - b^t, evaluated in f64 (no f32 cancellation)
+
+  // ---- phase 1: every block computes every segment's norm identically
+  for (int sgi = 0; sgi < n_seg; ++sgi) {
+    const int lo = segs.off[sgi], hi = segs.off[sgi + 1];
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += ADAM_THREADS) {
+      const float gi = g[i] * grad_scale;
+      acc += (double)gi * (double)gi;
+    }
+    const double tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) {
+      const float nrm = (float)sqrt(tot);
+      // optax.clip_by_global_norm: trigger = n < c ; else (g / n) * c
+      s_clip[sgi] = (nrm < max_norm) ? -1.0f : nrm;
+      const double t = (double)(count[sgi] + 1);
+      s_bc1[sgi] = (float)(1.0 - pow((double)b1, t));
+      s_bc2[sgi] = (float)(1.0 - pow((double)b2, t));
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: slice update
+  const int total = segs.off[n_seg];
+  const int gid = blockIdx.x * ADAM_THREADS + threadIdx.x;
+  const int stride = gridDim.x * ADAM_THREADS;
+  for (int i = gid; i < total; i += stride) {
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+      if (k < n_seg && i >= segs.off[k]) sgi = k;
+    const int cnt = count[sgi];
+    float lr = segs.lr[sgi];
+    if (decay) {
+      // mava/utils/training.py:36-42: frac = 1 - (count // (epochs*minibatches)) / num_updates
+      const float frac = 1.0f - (float)(cnt / steps_per_update) / (float)num_updates;
+      lr = lr * frac;
+    }
+    float gi = g[i] * grad_scale;
+    const float nrm = s_clip[sgi];
+    if (nrm >= 0.0f) gi = (gi / nrm) * max_norm;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float mhat = mi / s_bc1[sgi];
+    const float vhat = vi / s_bc2[sgi];
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr * (mhat / (sqrtf(vhat) + eps));
+  }
+
+  // ---- metrics (ff_mappo.py:255-265): loss_sums = [actor_loss, entropy, value_loss] summed
+  // over replicas/ranks of per-replica means.
+  if (metrics_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float actor_loss = loss_sums[0] * grad_scale;
+    const float entropy = loss_sums[1] * grad_scale;
+    const float value_loss = loss_sums[2] * grad_scale;
+    metrics_out[0] = (actor_loss - ent_coef * entropy) + vf_coef * value_loss;  // total_loss
+    metrics_out[1] = value_loss;
+    metrics_out[2] = actor_loss;
+    metrics_out[3] = entropy;
+  }
+}
+
+// The grid is ordered so the counter increment cannot race with readers: counts are bumped by
+// a separate 1-thread kernel on the same stream after the update kernel.
+__global__ void bump_counts_kernel(int32_t* count, int n_seg) {
+  if (threadIdx.x < n_seg) count[threadIdx.x] += 1;
+}
+
+// out[i] = sum_b slab[b][i] for i < n, b ascending (deterministic).  Optionally accumulates onto
+// the existing out (used when several update-batch replicas add into one flat gradient).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab,
+                                                          int n_slab, long slab_stride, int n,
+                                                          int accumulate,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.0f;
+  int b = 0;
+  for (; b + 4 <= n_slab; b += 4) {
+    const float a0 = slab[(long)(b + 0) * slab_stride + i];
+    const float a1 = slab[(long)(b + 1) * slab_stride + i];
+    const float a2 = slab[(long)(b + 2) * slab_stride + i];
+    const float a3 = slab[(long)(b + 3) * slab_stride + i];
+    acc = (((acc + a0) + a1) + a2) + a3;
+  }
+  for (; b < n_slab; ++b) acc += slab[(long)b * slab_stride + i];
+  out[i] = accumulate ? (out[i] + acc) : acc;
+}
+
+}  // namespace
+
+extern "C" int mava_clip_adam(float* p, const float* g, float* m, float* v, int32_t* count,
+                              const int* seg_off, const float* seg_lr, int n_seg,
+                              float grad_scale, float max_norm, int decay, int steps_per_update,
+                              int num_updates, float b1, float b2, float eps,
+                              const float* loss_sums, float vf_coef, float ent_coef,
+                              float* metrics_out, hipStream_t s) {
+  MAVA_ARG_CHECK(n_seg >= 1 && n_seg <= MAX_SEG, 0, "mava_clip_adam: n_seg=%d out of [1,%d]",
+                 n_seg, MAX_SEG);
+  MAVA_ARG_CHECK(p && g && m && v && count && seg_off && seg_lr, 1,
+                 "mava_clip_adam: null pointer argument");
+  MAVA_ARG_CHECK(metrics_out == nullptr || loss_sums != nullptr, 2,
+                 "mava_clip_adam: metrics_out needs loss_sums");
+  MAVA_ARG_CHECK(!decay || (steps_per_update > 0 && num_updates > 0), 3,
+                 "mava_clip_adam: decay needs steps_per_update>0 and num_updates>0");
+  AdamSegs segs;
+  for (int i = 0; i <= n_seg; ++i) {
+    segs.off[i] = seg_off[i];
+    MAVA_ARG_CHECK(i == 0 || seg_off[i] >= seg_off[i - 1], 4,
+                   "mava_clip_adam: seg_off must be non-decreasing");
+  }
+  MAVA_ARG_CHECK(seg_off[0] == 0, 5, "mava_clip_adam: seg_off[0] must be 0");
+  for (int i = 0; i < n_seg; ++i) segs.lr[i] = seg_lr[i];
+  const int total = seg_off[n_seg];
+  if (total == 0) return MAVA_OK;
+  int blocks = mava_cdiv(total, ADAM_THREADS * 4);
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, p, g, m, v, count,
+                     segs, n_seg, grad_scale, max_norm, decay, steps_per_update, num_updates, b1,
+                     b2, eps, loss_sums, vf_coef, ent_coef, metrics_out);
+  MAVA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bump_counts_kernel, dim3(1), dim3(64), 0, s, count, n_seg);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_slab_reduce_f32(const float* slab, int n_slab, long slab_stride, int n,
+                                    int accumulate, float* out, hipStream_t s) {
+  MAVA_ARG_CHECK(n >= 0 && n_slab >= 0 && slab_stride >= n, 0,
+                 "mava_slab_reduce_f32: bad shape n=%d n_slab=%d stride=%ld", n, n_slab,
+                 slab_stride);
+  if (n == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(slab && out, 1, "mava_slab_reduce_f32: null pointer argument");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(mava_cdiv(n, 256)), dim3(256), 0, s, slab, n_slab,
+                     slab_stride, n, accumulate, out);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}

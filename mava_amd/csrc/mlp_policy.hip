@@ -1,0 +1,239 @@
+// Acting-side kernels (K1 + K2 + K3 of SURVEY §2.1): fused actor forward + action mask +
+// categorical sample + log-prob, and critic forward, in ONE launch per environment step.
+//
+// Reference: mava/systems/ppo/ff_mappo.py:80-85 (_env_step: actor_apply, critic_apply,
+// sample, log_prob), mava/networks.py:172-207, mava/distributions.py:146-165.
+// Sampling is Gumbel-max like jax.random.categorical, but on this library's own Philox4x32-10
+// stream (bit parity with JAX threefry is not a goal; parity tests compare against the oracle's
+// restatement of the same Philox stream).
+//
+// Launch shape: 256-thread blocks (4 waves); each wave runs whole 32-row tiles through all
+// three layers in registers (mlp_core.h).  Blocks [0, nblk_actor) serve the actor, the rest
+// the critic, so one launch covers 2 * ceil(R/32) wave-tiles (1024 at the BASELINE config-2
+// shape: one per SIMD).  W2/W3/biases are staged in LDS once per block.
+#include "mlp_core.h"
+
+namespace {
+
+struct FwdTask {
+  const float* params;
+  const float* x;   // (rows_x, din)
+  int din;
+  int no;
+  int xshare;       // x row = agent_row / xshare (A when all agents of an env share one input row)
+  int xv;           // x load vector width (1/2/4)
+  int R;            // agent rows to evaluate
+};
+
+template <int NO>
+__device__ __forceinline__ void forward_tile(const FwdTask& tk, const float* lds, int row, bool valid,
+                                             int h, int j, float (&y)[NO]) {
+  const long xr = valid ? (long)(row / tk.xshare) : 0;
+  const float* xrow = tk.x + xr * tk.din;
+  const float* W1g = tk.params;
+  f32x16 z1[4], z2[4];
+  if (tk.xv == 4) {
+    mlp_l1_forward<4>(xrow, tk.din, W1g, lds + MlpLds<NO>::B1, h, j, z1);
+  } else if (tk.xv == 2) {
+    mlp_l1_forward<2>(xrow, tk.din, W1g, lds + MlpLds<NO>::B1, h, j, z1);
+  } else {
+    mlp_l1_forward<1>(xrow, tk.din, W1g, lds + MlpLds<NO>::B1, h, j, z1);
+  }
+  mlp_relu(z1);
+  mlp_l2_forward(z1, lds + MlpLds<NO>::W2, lds + MlpLds<NO>::B2, h, j, z2);
+  mlp_relu(z2);
+  mlp_head_forward<NO>(z2, lds + MlpLds<NO>::W3, lds + MlpLds<NO>::B3, h, y);
+}
+
+// Raw forward: out[row][o] = network(x[row / xshare])[o]
+template <int NO>
+__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(FwdTask tk, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  mlp_fill_lds<NO>(lds, tk.params, tk.din, tk.no, 256);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
+  const int ntiles = (tk.R + 31) / 32;
+  for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += gridDim.x * 4) {
+    const int row = tile * 32 + j;
+    const bool valid = row < tk.R;
+    float y[NO];
+    forward_tile<NO>(tk, lds, row, valid, h, j, y);
+    if (valid && h == 0) {
+      for (int o = 0; o < tk.no && o < NO; ++o) out[(long)row * tk.no + o] = y[o];
+    }
+  }
+}
+
+struct StepOut {
+  int32_t* action;      // (R)
+  float* log_prob;      // (R)
+  float* value;         // (R_critic * vbroadcast)
+  float* logits;        // optional (R, no) raw (unmasked) logits, for parity tests
+  const int32_t* forced_action;  // optional: evaluate log_prob of given actions instead of sampling
+};
+
+template <int NOA>
+__global__ __launch_bounds__(256, 2) void policy_step_kernel(FwdTask actor, FwdTask critic,
+                                                             int nblk_actor,
+                                                             const uint8_t* __restrict__ mask,
+                                                             uint32_t seed_lo, uint32_t seed_hi,
+                                                             uint32_t step, uint32_t row_offset,
+                                                             int vbroadcast, int greedy,
+                                                             StepOut out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const bool is_actor = (int)blockIdx.x < nblk_actor;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
+  if (is_actor) {
+    mlp_fill_lds<NOA>(lds, actor.params, actor.din, actor.no, 256);
+    __syncthreads();
+    const int ntiles = (actor.R + 31) / 32;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nblk_actor * 4) {
+      const int row = tile * 32 + j;
+      const bool valid = row < actor.R;
+      float y[NOA];
+      forward_tile<NOA>(actor, lds, row, valid, h, j, y);
+      const int no = actor.no;
+      Categorical<NOA> cat;
+      cat.build(y, (mask != nullptr && valid) ? (mask + (long)row * no) : nullptr, no);
+      int a = 0;
+      if (out.forced_action != nullptr) {
+        a = valid ? out.forced_action[row] : 0;
+      } else if (greedy) {
+        float best = -FLT_MAX;
+#pragma unroll
+        for (int o = 0; o < NOA; ++o)
+          if (o < no && cat.z[o] > best) { best = cat.z[o]; a = o; }
+      } else {
+        // Gumbel-max: argmax_o z[o] - log(-log(u_o)), first index wins ties
+        float best = -FLT_MAX;
+        const uint32_t gid = row_offset + (uint32_t)row;
+#pragma unroll
+        for (int c = 0; c < (NOA + 3) / 4; ++c) {
+          Philox4 rnd = philox4x32_10(gid, step, (uint32_t)c, 0x504f4c49u /*"POLI"*/, seed_lo, seed_hi);
+          const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int o = 4 * c + q;
+            if (o < NOA && o < no) {
+              const float u = u01_open(wds[q]);
+              const float g = -logf(-logf(u));
+              const float sc = cat.z[o] + g;
+              if (sc > best) { best = sc; a = o; }
+            }
+          }
+        }
+      }
+      float lp = 0.0f;
+#pragma unroll
+      for (int o = 0; o < NOA; ++o)
+        if (o == a) lp = cat.logp[o];
+      if (valid && h == 0) {
+        out.action[row] = a;
+        out.log_prob[row] = lp;
+        if (out.logits != nullptr)
+          for (int o = 0; o < no && o < NOA; ++o) out.logits[(long)row * no + o] = y[o];
+      }
+    }
+  } else {
+    const int bid = blockIdx.x - nblk_actor;
+    const int nblk = gridDim.x - nblk_actor;
+    mlp_fill_lds<1>(lds, critic.params, critic.din, 1, 256);
+    __syncthreads();
+    const int ntiles = (critic.R + 31) / 32;
+    for (int tile = bid * 4 + w; tile < ntiles; tile += nblk * 4) {
+      const int row = tile * 32 + j;
+      const bool valid = row < critic.R;
+      float y[1];
+      forward_tile<1>(critic, lds, row, valid, h, j, y);
+      if (valid && h == 0) {
+        for (int b = 0; b < vbroadcast; ++b) out.value[(long)row * vbroadcast + b] = y[0];
+      }
+    }
+  }
+}
+
+int pick_xv(const float* x, int din) {
+  const uintptr_t a = (uintptr_t)x;
+  if (din % 4 == 0 && a % 16 == 0) return 4;
+  if (din % 2 == 0 && a % 8 == 0) return 2;
+  return 1;
+}
+
+template <int NO>
+size_t lds_bytes() { return (size_t)MlpLds<NO>::END * sizeof(float); }
+
+}  // namespace
+
+extern "C" int mava_mlp_param_count(int din, int n_out) { return mlp_param_count(din, n_out); }
+
+extern "C" int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x,
+                                    int x_share, int rows, float* out, hipStream_t s) {
+  MAVA_ARG_CHECK(din >= 1 && n_out >= 1 && n_out <= 32, 0,
+                 "mava_mlp_forward_f32: din=%d n_out=%d unsupported (n_out <= 32)", din, n_out);
+  MAVA_ARG_CHECK(rows >= 0 && x_share >= 1, 1, "mava_mlp_forward_f32: rows=%d x_share=%d", rows, x_share);
+  if (rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(params && x && out, 2, "mava_mlp_forward_f32: null pointer argument");
+  FwdTask tk = {params, x, din, n_out, x_share, pick_xv(x, din), rows};
+  const int ntiles = mava_cdiv(rows, 32);
+  int blocks = mava_cdiv(ntiles, 4);
+  if (blocks > 512) blocks = 512;
+#define LAUNCH_FWD(NO)                                                                        \
+  do {                                                                                        \
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<NO>,                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                       (int)lds_bytes<NO>()));                                \
+    hipLaunchKernelGGL(mlp_forward_kernel<NO>, dim3(blocks), dim3(256), lds_bytes<NO>(), s, tk, \
+                       out);                                                                  \
+  } while (0)
+  if (n_out == 1) LAUNCH_FWD(1);
+  else if (n_out <= 8) LAUNCH_FWD(8);
+  else if (n_out <= 16) LAUNCH_FWD(16);
+  else LAUNCH_FWD(32);
+#undef LAUNCH_FWD
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
+                                    const float* agents_view, const uint8_t* action_mask,
+                                    const float* critic_params, int critic_din,
+                                    const float* critic_input, int critic_share, int critic_rows,
+                                    int value_broadcast, int rows, uint64_t seed, uint32_t step,
+                                    uint32_t row_offset, int greedy, const int32_t* forced_action,
+                                    int32_t* action, float* log_prob, float* value, float* logits,
+                                    hipStream_t s) {
+  MAVA_ARG_CHECK(actor_din >= 1 && critic_din >= 1 && n_actions >= 1 && n_actions <= 32, 0,
+                 "mava_policy_step_f32: actor_din=%d critic_din=%d n_actions=%d unsupported",
+                 actor_din, critic_din, n_actions);
+  MAVA_ARG_CHECK(rows >= 0 && critic_rows >= 0 && critic_share >= 1 && value_broadcast >= 1, 1,
+                 "mava_policy_step_f32: bad row counts");
+  if (rows == 0 && critic_rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(actor_params && agents_view && critic_params && critic_input && action &&
+                     log_prob && value,
+                 2, "mava_policy_step_f32: null pointer argument");
+  FwdTask ta = {actor_params, agents_view, actor_din, n_actions, 1, pick_xv(agents_view, actor_din), rows};
+  FwdTask tc = {critic_params, critic_input, critic_din, 1, critic_share,
+                pick_xv(critic_input, critic_din), critic_rows};
+  int nba = mava_cdiv(mava_cdiv(rows, 32), 4);
+  int nbc = mava_cdiv(mava_cdiv(critic_rows, 32), 4);
+  if (nba > 256) nba = 256;
+  if (nbc > 256) nbc = 256;
+  if (nba < 1) nba = 1;
+  if (nbc < 1) nbc = 1;
+  StepOut so = {action, log_prob, value, logits, forced_action};
+  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+#define LAUNCH_STEP(NO)                                                                         \
+  do {                                                                                          \
+    const size_t lb = lds_bytes<NO>() > lds_bytes<1>() ? lds_bytes<NO>() : lds_bytes<1>();      \
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)policy_step_kernel<NO>,                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));   \
+    hipLaunchKernelGGL(policy_step_kernel<NO>, dim3(nba + nbc), dim3(256), lb, s, ta, tc, nba,  \
+                       action_mask, slo, shi, step, row_offset, value_broadcast, greedy, so);   \
+  } while (0)
+  if (n_actions <= 8) LAUNCH_STEP(8);
+  else if (n_actions <= 16) LAUNCH_STEP(16);
+  else LAUNCH_STEP(32);
+#undef LAUNCH_STEP
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}

@@ -1,0 +1,154 @@
+// Synthetic RWARE-shaped environment step (SURVEY §8d "synthetic inputs"): the environment is
+// NOT simulated (Jumanji's RobotWarehouse is third-party JAX code that is not available); this
+// kernel produces observations / masks / rewards / dones with RWARE's shapes and statistics and
+// reproduces the wrapper semantics the learner records:
+//   * AgentIDWrapper (mava/wrappers/observation.py:41-53): one-hot agent id prepended to
+//     agents_view only;
+//   * RwareWrapper / get_global_state (mava/wrappers/jumanji.py:53-59,128-143): global_state =
+//     concatenation of the RAW agent views (identical for every agent), team reward repeated per
+//     agent, step_count per agent;
+//   * AutoResetWrapper (mava/wrappers/auto_reset_wrapper.py:88-101): a terminal step returns the
+//     reset observation with step_count 0;
+//   * RecordEpisodeMetrics (mava/wrappers/episode_metrics.py:78-111): episode_return /
+//     episode_length / is_terminal_step bookkeeping (return uses mean over agents of the reward).
+// Distribution (seeded Philox4x32-10, counter = (entity, global step, word group, stream)):
+//   agents_view = [one-hot id (A) | 2 grid coordinates U{0..9} | O-2 Bernoulli(51/256) bits]
+//   action_mask = all legal except action 1 which is illegal w.p. 51/256
+//   reward      = 1.0 w.p. 0.02 (team), done = step_count reaches time_limit or w.p. 0.002
+// Restated bit-for-bit in oracle/synth_env.py.
+#include "common.h"
+
+namespace {
+
+constexpr uint32_t ENV_STREAM = 0x454E5653u;  // "ENVS"
+
+struct SynthArgs {
+  int E, A, O, nA;
+  int gs_tiles;       // 1: global_state (E, A*O) shared by the agents; A: (E, A, A*O) tiled copy
+  int time_limit;
+  uint32_t seed_lo, seed_hi;
+  uint32_t t;         // global step counter (unique per call)
+  uint32_t env_offset;  // global id of env 0 (rank / replica offset)
+  // state: step_count (E, A) - one private copy per agent thread (no cross-thread hazard); rest (E)
+  int32_t* step_count;
+  float* run_return;
+  int32_t* run_length;
+  float* ep_return;
+  int32_t* ep_length;
+  // outputs
+  float* agents_view;   // (E, A, A+O)
+  float* global_state;  // (E, gs_tiles, A*O)
+  uint8_t* action_mask; // (E, A, nA)
+  int32_t* obs_step_count;  // (E, A)
+  float* reward;        // (E, A) or null (reset)
+  uint8_t* done;        // (E, A) or null
+  float* info_return;   // (E) or null
+  int32_t* info_length; // (E) or null
+  uint8_t* info_terminal;  // (E) or null
+  int is_reset;
+};
+
+// one thread per (env, agent)
+__global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int E = a.E, A = a.A, O = a.O;
+  if (gid >= E * A) return;
+  const int e = gid / A, ag = gid - e * A;
+  const uint32_t env_id = a.env_offset + (uint32_t)e;
+
+  // ---- per-env draws (recomputed by every agent thread of the env: identical values)
+  Philox4 ev = philox4x32_10(env_id, a.t, 0u, ENV_STREAM ^ 1u, a.seed_lo, a.seed_hi);
+  const int sc_old = a.is_reset ? 0 : a.step_count[gid];
+  const float rew = (!a.is_reset && u01_open(ev.x) < 0.02f) ? 1.0f : 0.0f;
+  const int sc_new = sc_old + 1;
+  const bool term = !a.is_reset && ((sc_new >= a.time_limit) || (u01_open(ev.y) < 0.002f));
+  const int sc_obs = (a.is_reset || term) ? 0 : sc_new;
+
+  // ---- this agent's raw view
+  float* av = a.agents_view + ((long)e * A + ag) * (A + O);
+  for (int i = 0; i < A; ++i) av[i] = (i == ag) ? 1.0f : 0.0f;
+  const uint32_t ent = env_id * (uint32_t)A + (uint32_t)ag;
+  Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
+  float* raw = av + A;
+  if (O > 0) raw[0] = (float)(cm.x % 10u);
+  if (O > 1) raw[1] = (float)(cm.y % 10u);
+  const int nchunk = (O - 2 + 15) / 16;
+  for (int c = 0; c < nchunk; ++c) {
+    Philox4 r = philox4x32_10(ent, a.t, (uint32_t)c, ENV_STREAM, a.seed_lo, a.seed_hi);
+    const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int f = 2 + 16 * c + q;
+      if (f < O) raw[f] = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
+    }
+  }
+  // global state: raw view of agent ag at column block ag, in every tile
+  for (int tl = 0; tl < a.gs_tiles; ++tl) {
+    float* gs = a.global_state + ((long)e * a.gs_tiles + tl) * ((long)A * O) + (long)ag * O;
+    for (int f = 0; f < O; ++f) gs[f] = raw[f];
+  }
+  uint8_t* mk = a.action_mask + ((long)e * A + ag) * a.nA;
+  for (int i = 0; i < a.nA; ++i) mk[i] = 1;
+  if (a.nA > 1 && ((cm.z & 0xFFu) < 51u)) mk[1] = 0;
+  a.obs_step_count[(long)e * A + ag] = sc_obs;
+  a.step_count[gid] = sc_obs;
+
+  if (!a.is_reset) {
+    a.reward[(long)e * A + ag] = rew;
+    a.done[(long)e * A + ag] = term ? 1 : 0;
+  }
+  // ---- per-env state and episode metrics (agent 0's thread)
+  if (ag == 0) {
+    if (a.is_reset) {
+      a.run_return[e] = 0.0f;
+      a.run_length[e] = 0;
+      a.ep_return[e] = 0.0f;
+      a.ep_length[e] = 0;
+    } else {
+      // episode_metrics.py:88-111 (mean over agents of a repeated team reward == the reward)
+      const float new_ret = a.run_return[e] + rew;
+      const int new_len = a.run_length[e] + 1;
+      const float ret_info = term ? new_ret : a.ep_return[e];
+      const int len_info = term ? new_len : a.ep_length[e];
+      a.info_return[e] = ret_info;
+      a.info_length[e] = len_info;
+      a.info_terminal[e] = term ? 1 : 0;
+      a.run_return[e] = term ? 0.0f : new_ret;
+      a.run_length[e] = term ? 0 : new_len;
+      a.ep_return[e] = ret_info;
+      a.ep_length[e] = len_info;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int time_limit,
+                                     uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
+                                     int32_t* step_count, float* run_return, int32_t* run_length,
+                                     float* ep_return, int32_t* ep_length, float* agents_view,
+                                     float* global_state, uint8_t* action_mask,
+                                     int32_t* obs_step_count, float* reward, uint8_t* done,
+                                     float* info_return, int32_t* info_length,
+                                     uint8_t* info_terminal, hipStream_t s) {
+  MAVA_ARG_CHECK(E >= 0 && A >= 1 && O >= 2 && n_actions >= 1 && time_limit >= 1, 0,
+                 "mava_synth_rware_step: bad shape E=%d A=%d O=%d nA=%d", E, A, O, n_actions);
+  MAVA_ARG_CHECK(gs_tiles == 1 || gs_tiles == A, 1, "mava_synth_rware_step: gs_tiles must be 1 or A");
+  if (E == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(step_count && run_return && run_length && ep_return && ep_length && agents_view &&
+                     global_state && action_mask && obs_step_count,
+                 2, "mava_synth_rware_step: null state/observation pointer");
+  MAVA_ARG_CHECK(is_reset || (reward && done && info_return && info_length && info_terminal), 3,
+                 "mava_synth_rware_step: null transition pointer");
+  SynthArgs a;
+  a.E = E; a.A = A; a.O = O; a.nA = n_actions; a.gs_tiles = gs_tiles; a.time_limit = time_limit;
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.t = t; a.env_offset = env_offset;
+  a.step_count = step_count; a.run_return = run_return; a.run_length = run_length;
+  a.ep_return = ep_return; a.ep_length = ep_length; a.agents_view = agents_view;
+  a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;
+  a.reward = reward; a.done = done; a.info_return = info_return; a.info_length = info_length;
+  a.info_terminal = info_terminal; a.is_reset = is_reset;
+  hipLaunchKernelGGL(synth_rware_kernel, dim3(mava_cdiv((long)E * A, 256)), dim3(256), 0, s, a);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}

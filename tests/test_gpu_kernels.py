@@ -1,0 +1,317 @@
+"""GPU parity of the individual HIP kernels against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox, ppo_oracle as po
+from tests.conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+# ------------------------------------------------------------------------------------------ GAE
+@pytest.mark.parametrize(
+    "T,N,rec",
+    [(8, 8, False), (128, 32, False), (128, 16384, False), (128, 16384, True), (5, 7, False), (37, 130, True),
+     (300, 66, False), (1, 64, False), (128, 4100, True)],
+)
+def test_gae_matches_oracle(dev, T, N, rec):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(T * 1000 + N)
+    r = rng.standard_normal((T, N)).astype(np.float32)
+    v = rng.standard_normal((T, N)).astype(np.float32)
+    d = rng.random((T, N)) < (0.05 if N < 1000 else 1 / 500)
+    lv = rng.standard_normal(N).astype(np.float32)
+    ld = (rng.random(N) < 0.1) if rec else None
+    adv64, tgt64 = po.gae(r, v, d, lv, 0.99, 0.95, last_done=ld)
+    adv32, tgt32 = po.gae(r, v, d, lv, 0.99, 0.95, last_done=ld, dtype=np.float32)
+    adv, tgt = ops.gae(_t(r, dev), _t(v, dev), _t(d, dev), _t(lv, dev), 0.99, 0.95,
+                       last_done=None if ld is None else _t(ld, dev))
+    torch.cuda.synchronize()
+    # north_star: advantages/returns within 1e-5 rtol (tolerance form of BASELINE.md §2)
+    assert_close(adv.cpu().numpy(), adv64, 1e-5, "adv vs f64")
+    assert_close(tgt.cpu().numpy(), tgt64, 1e-5, "tgt vs f64")
+    assert_close(adv.cpu().numpy(), adv32, 1e-5, "adv vs f32")
+
+
+def test_gae_properties(dev):
+    """lambda=gamma=1, no dones: adv_t = sum_{s>=t} r_s + last_val - V_t; all-done: adv = r - V."""
+    from mava_amd import ops
+
+    T, N = 128, 256
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal((T, N)).astype(np.float32)
+    v = rng.standard_normal((T, N)).astype(np.float32)
+    lv = rng.standard_normal(N).astype(np.float32)
+    z = np.zeros((T, N), bool)
+    adv, _ = ops.gae(_t(r, dev), _t(v, dev), _t(z, dev), _t(lv, dev), 1.0, 1.0)
+    want = np.cumsum(r[::-1].astype(np.float64), 0)[::-1] + lv - v
+    assert_close(adv.cpu().numpy(), want, 1e-5, "telescoping")
+    adv, tgt = ops.gae(_t(r, dev), _t(v, dev), _t(~z, dev), _t(lv, dev), 0.99, 0.95)
+    assert np.array_equal(adv.cpu().numpy(), r - v)
+    assert_close(tgt.cpu().numpy(), r.astype(np.float64), 1e-6, "targets all-done")
+
+
+def test_gae_empty(dev):
+    from mava_amd import ops
+
+    e = torch.empty((0, 16), device=dev)
+    adv, tgt = ops.gae(e, e.clone(), torch.empty((0, 16), dtype=torch.uint8, device=dev), torch.zeros(16, device=dev), 0.99, 0.95)
+    assert adv.shape == (0, 16)
+
+
+# ----------------------------------------------------------------------------------------- Adam
+@pytest.mark.parametrize("decay", [False, True])
+@pytest.mark.parametrize("big_grad", [False, True])
+def test_clip_adam_matches_oracle(dev, decay, big_grad):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(11 + decay + 2 * big_grad)
+    sizes = [26245, 50561]
+    off = [0, sizes[0], sizes[0] + sizes[1]]
+    P = off[-1]
+    p0 = rng.standard_normal(P).astype(np.float32) * 0.1
+    m0 = rng.standard_normal(P).astype(np.float32) * 1e-3
+    v0 = (rng.random(P).astype(np.float32)) * 1e-5
+    U_D = 4
+    lrs = [2.5e-4, 1e-3]
+    count0 = [9, 9]
+    p, m, v = _t(p0, dev), _t(m0, dev), _t(v0, dev)
+    count = torch.tensor(count0, dtype=torch.int32, device=dev)
+    pr, mr, vr = p0.astype(np.float64), m0.astype(np.float64), v0.astype(np.float64)
+    cr = list(count0)
+    loss = rng.random(3).astype(np.float32)
+    metrics = torch.zeros(4, device=dev)
+    for it in range(3):
+        gsum = rng.standard_normal(P).astype(np.float32) * (10.0 if big_grad else 1e-3)
+        ops.clip_adam(p, _t(gsum, dev), m, v, count, off, lrs, grad_scale=1.0 / U_D, max_norm=0.5, decay=decay,
+                      steps_per_update=8, num_updates=10, loss_sums=_t(loss, dev), vf_coef=0.5, ent_coef=0.01,
+                      metrics_out=metrics)
+        for s in range(2):
+            sl = slice(off[s], off[s + 1])
+            lr = po.learning_rate(lrs[s], cr[s], decay, 4, 2, 10)
+            pr[sl], mr[sl], vr[sl], cr[s] = po.clip_adam(pr[sl], gsum[sl].astype(np.float64) / U_D, mr[sl], vr[sl],
+                                                        cr[s], lr, 0.5)
+    torch.cuda.synchronize()
+    assert count.cpu().tolist() == cr
+    # f32 arithmetic vs the f64 oracle: elements with v ~ 1e-10 take steps of ~1e-2, whose f32 rounding
+    # (~1e-7 relative per op, also present in a float32 NumPy run of the oracle) bounds the agreement.
+    assert_close(p.cpu().numpy(), pr, 1e-5, "params")
+    assert_close(p.cpu().numpy() - p0, pr - p0, 1e-4, "param update")
+    assert_close(m.cpu().numpy(), mr, 1e-5, "mu")
+    assert_close(v.cpu().numpy(), vr, 1e-5, "nu")
+    a, e, vl = (loss / U_D).tolist()
+    assert_close(metrics.cpu().numpy(), np.array([a - 0.01 * e + 0.5 * vl, vl, a, e]), 1e-6, "metrics")
+
+
+def test_slab_reduce(dev):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(5)
+    slab = rng.standard_normal((37, 1000)).astype(np.float32)
+    out = torch.zeros(900, device=dev)
+    ops.slab_reduce(_t(slab, dev), 900, out)
+    assert_close(out.cpu().numpy(), slab[:, :900].astype(np.float64).sum(0), 1e-6, "slab")
+    ops.slab_reduce(_t(slab, dev), 900, out, accumulate=True)
+    assert_close(out.cpu().numpy(), 2 * slab[:, :900].astype(np.float64).sum(0), 1e-6, "slab acc")
+
+
+# ------------------------------------------------------------------------------------------ MLP
+def _net(rng, din, no, head_scale, bias_noise=0.1):
+    p = po.init_mlp(rng, din, no, head_scale)
+    p = p._replace(b1=rng.standard_normal(128) * bias_noise, b2=rng.standard_normal(128) * bias_noise,
+                   b3=rng.standard_normal(no) * bias_noise)
+    return po.mlp_flatten(p)
+
+
+@pytest.mark.parametrize("din,no,rows,share", [(70, 5, 64, 1), (264, 1, 100, 4), (66, 14, 33, 1), (7, 3, 1, 1),
+                                               (129, 32, 257, 1), (264, 1, 16384, 4)])
+def test_mlp_forward_matches_oracle(dev, din, no, rows, share):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(din * 7 + no)
+    flat = _net(rng, din, no, 1.0)
+    rows_x = (rows + share - 1) // share
+    x = rng.standard_normal((rows_x, din))
+    y = ops.mlp_forward(_t(flat, dev, torch.float32), din, no, _t(x, dev, torch.float32), rows=rows, x_share=share)
+    torch.cuda.synchronize()
+    x32 = x.astype(np.float32).astype(np.float64)
+    f32 = flat.astype(np.float32).astype(np.float64)
+    want = po.mlp_forward(po.mlp_unflatten(f32, din, no), x32[np.arange(rows) // share])
+    assert_close(y.cpu().numpy(), want, 1e-5, "mlp forward")
+
+
+def test_policy_step_matches_oracle(dev):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(2024)
+    E, A, O, nA = 96, 4, 66, 5
+    rows = E * A
+    fa = _net(rng, O + A, nA, 1.0).astype(np.float32)  # head scale 1.0 => non-trivial distribution
+    fc = _net(rng, A * O, 1, 1.0).astype(np.float32)
+    av = rng.standard_normal((rows, O + A)).astype(np.float32)
+    gs = rng.standard_normal((E, A * O)).astype(np.float32)
+    mask = rng.random((rows, nA)) > 0.2
+    mask[:, 0] = True
+    seed, step = 0x1234ABCD5678EF01, 77
+    action, logp, value, logits = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                                  n_actions=nA, critic_share=A, seed=seed, step=step,
+                                                  row_offset=1000, want_logits=True)
+    torch.cuda.synchronize()
+    pa = po.mlp_unflatten(fa.astype(np.float64), O + A, nA)
+    pc = po.mlp_unflatten(fc.astype(np.float64), A * O, 1)
+    y = po.mlp_forward(pa, av.astype(np.float64))
+    assert_close(logits.cpu().numpy(), y, 1e-5, "logits")
+    z = po.masked_logits(y, mask)
+    lsm = po.log_softmax(z)
+    u = philox.policy_uniforms(seed, step, rows, nA, row_offset=1000)
+    a_or = po.gumbel_argmax(z, u)
+    a = action.cpu().numpy()
+    # f32 vs f64 Gumbel scores may flip near-ties only
+    g = -np.log(-np.log(u.astype(np.float64)))
+    sc = z + g
+    diff = a != a_or
+    if diff.any():
+        gap = np.abs(sc[np.arange(rows), a] - sc[np.arange(rows), a_or])[diff]
+        assert gap.max() < 1e-4, gap.max()
+    assert diff.mean() < 0.01
+    assert mask[np.arange(rows), a].all(), "sampled an illegal action"
+    assert_close(logp.cpu().numpy(), lsm[np.arange(rows), a], 1e-5, "log_prob")
+    v = po.mlp_forward(pc, gs.astype(np.float64))[:, 0]
+    assert_close(value.cpu().numpy(), np.repeat(v, A), 1e-5, "value")
+    # forced actions + greedy
+    forced = torch.from_numpy(a_or).to(dev)
+    _, logp2, _, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                     n_actions=nA, critic_share=A, seed=seed, step=step, forced_action=forced)
+    assert_close(logp2.cpu().numpy(), lsm[np.arange(rows), a_or], 1e-5, "forced log_prob")
+    ag, _, _, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev), n_actions=nA,
+                                  critic_share=A, seed=seed, step=step, greedy=True)
+    assert (ag.cpu().numpy() == np.argmax(z, -1)).mean() > 0.995
+
+
+def test_policy_sampling_distribution(dev):
+    """Sampled actions follow softmax(masked logits): chi-square on one repeated state."""
+    from mava_amd import ops
+
+    rng = np.random.default_rng(9)
+    O, nA, rows = 20, 5, 1 << 16
+    fa = _net(rng, O, nA, 2.0).astype(np.float32)
+    fc = _net(rng, O, 1, 1.0).astype(np.float32)
+    x1 = rng.standard_normal((1, O)).astype(np.float32)
+    av = np.repeat(x1, rows, 0)
+    mask = np.ones((rows, nA), bool)
+    mask[:, 3] = False
+    action, _, _, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(av, dev), n_actions=nA,
+                                      seed=5, step=1)
+    a = action.cpu().numpy()
+    y = po.mlp_forward(po.mlp_unflatten(fa.astype(np.float64), O, nA), x1.astype(np.float64))
+    p = np.exp(po.log_softmax(po.masked_logits(y, mask[:1])))[0]
+    cnt = np.bincount(a, minlength=nA)
+    assert cnt[3] == 0
+    exp = p * rows
+    keep = exp > 0
+    chi2 = (((cnt - exp) ** 2)[keep] / exp[keep]).sum()
+    assert chi2 < 30.0, (chi2, cnt, exp)  # 3 dof; 30 is far in the tail
+
+
+# ---------------------------------------------------------------------------- PPO gradient kernels
+def _traj(rng, TE, A, O, nA, shared_gs=True):
+    rows = TE * A
+    av = rng.standard_normal((rows, O + A)).astype(np.float32)
+    gs = rng.standard_normal((TE if shared_gs else rows, A * O)).astype(np.float32)
+    mask = rng.random((rows, nA)) > 0.25
+    action = rng.integers(0, nA, rows).astype(np.int32)
+    mask[np.arange(rows), action] = True
+    old_lp = (-np.abs(rng.standard_normal(rows)) - 0.5).astype(np.float32)
+    adv = (rng.standard_normal(rows) * 2.0 + 0.3).astype(np.float32)
+    old_v = rng.standard_normal(rows).astype(np.float32)
+    tgt = (old_v + rng.standard_normal(rows) * 0.5).astype(np.float32)
+    return av, gs, mask, action, old_lp, adv, old_v, tgt
+
+
+@pytest.mark.parametrize("TE,A,O,nA,Rb,use_idx,n_slab", [(64, 4, 66, 5, 64, False, 3), (200, 4, 66, 5, 77, True, 8),
+                                                          (96, 2, 30, 14, 40, True, 2), (33, 1, 7, 3, 33, True, 1),
+                                                          (4096, 4, 66, 5, 2048, True, 256)])
+def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab):
+    from mava_amd import ops
+    from oracle import torch_ref
+
+    rng = np.random.default_rng(TE + nA)
+    av, gs, mask, action, old_lp, adv, old_v, tgt = _traj(rng, TE, A, O, nA)
+    din = O + A
+    flat = _net(rng, din, nA, 1.0).astype(np.float32)
+    if use_idx:
+        idx = rng.permutation(TE)[:Rb].astype(np.int32)
+        base = 0
+    else:
+        idx = np.arange(Rb, dtype=np.int32)
+        base = 0
+    rows_sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
+    # make old log-probs close to the current ones so that the clip range is exercised on both sides
+    y = po.mlp_forward(po.mlp_unflatten(flat.astype(np.float64), din, nA), av.astype(np.float64))
+    lsm = po.log_softmax(po.masked_logits(y, mask))
+    old_lp = (lsm[np.arange(TE * A), action] + rng.standard_normal(TE * A) * 0.25).astype(np.float32)
+
+    P = flat.size
+    slab = torch.zeros((n_slab, P + 2), device=dev)
+    stats = ops.adv_stats(_t(adv, dev), _t(idx, dev) if use_idx else None, base, Rb, A)
+    ops.ppo_actor_grad(_t(flat, dev), _t(av, dev), _t(mask, dev), _t(action, dev), _t(old_lp, dev), _t(adv, dev), stats,
+                       _t(idx, dev) if use_idx else None, base, Rb, A, nA, 0.2, 0.01, slab)
+    out = torch.zeros(P + 2, device=dev)
+    ops.slab_reduce(slab, P + 2, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+
+    args = (flat.astype(np.float64), din, nA, av[rows_sel].astype(np.float64), mask[rows_sel], action[rows_sel],
+            old_lp[rows_sel].astype(np.float64), adv[rows_sel].astype(np.float64), 0.2, 0.01)
+    tot, la, ent, g = po.actor_loss_and_grad(*args)
+    tot2, la2, ent2, g2 = torch_ref.actor_grad(*args)
+    assert_close(g, g2, 1e-9, "oracle vs torch autograd")  # the two CPU restatements agree
+    # north_star: PPO gradients within 1e-4 rtol (tolerance form of BASELINE.md §2)
+    assert_close(got[:P], g, 1e-4, "actor grad")
+    assert_close(got[P:], np.array([la, ent]), 1e-5, "actor loss/entropy", scale=1.0)
+
+
+@pytest.mark.parametrize("TE,A,O,Rb,use_idx,shared,n_slab", [(64, 4, 66, 64, False, True, 3), (200, 4, 66, 77, True, True, 8),
+                                                             (96, 2, 30, 40, True, False, 2), (33, 1, 9, 33, True, True, 1),
+                                                             (4096, 4, 66, 2048, True, True, 256)])
+def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab):
+    from mava_amd import ops
+    from oracle import torch_ref
+
+    rng = np.random.default_rng(TE + O)
+    av, gs, mask, action, old_lp, adv, old_v, tgt = _traj(rng, TE, A, O, 5, shared_gs=shared)
+    din = A * O
+    flat = _net(rng, din, 1, 1.0).astype(np.float32)
+    idx = rng.permutation(TE)[:Rb].astype(np.int32) if use_idx else np.arange(Rb, dtype=np.int32)
+    rows_sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
+    share = A if shared else 1
+    xsel = gs[rows_sel // share]
+    v_now = po.mlp_forward(po.mlp_unflatten(flat.astype(np.float64), din, 1), gs.astype(np.float64))[:, 0]
+    v_rows = v_now[np.arange(TE * A) // share]
+    old_v = (v_rows + rng.standard_normal(TE * A) * 0.2).astype(np.float32)  # both sides of the clip range
+    tgt = (v_rows + rng.standard_normal(TE * A)).astype(np.float32)
+
+    P = flat.size
+    slab = torch.zeros((n_slab, P + 2), device=dev)
+    ops.ppo_critic_grad(_t(flat, dev), _t(gs, dev), share, _t(old_v, dev), _t(tgt, dev), _t(idx, dev) if use_idx else None,
+                        0, Rb, A, 0.2, 0.5, slab)
+    out = torch.zeros(P + 2, device=dev)
+    ops.slab_reduce(slab, P + 2, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    args = (flat.astype(np.float64), din, xsel.astype(np.float64), old_v[rows_sel].astype(np.float64),
+            tgt[rows_sel].astype(np.float64), 0.2, 0.5)
+    tot, vl, g = po.critic_loss_and_grad(*args)
+    tot2, vl2, g2 = torch_ref.critic_grad(*args)
+    assert_close(g, g2, 1e-9, "oracle vs torch autograd")
+    assert_close(got[:P], g, 1e-4, "critic grad")
+    assert_close(got[P:P + 1], np.array([vl]), 1e-5, "value loss", scale=1.0)

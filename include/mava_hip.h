@@ -55,6 +55,12 @@ int mava_clip_adam(float* p, const float* g, float* m, float* v, int32_t* count,
 int mava_slab_reduce_f32(const float* slab, int n_slab, long slab_stride, int n, int accumulate,
                          float* out, mava_stream_t s);
 
+/* Same, with row columns [0,n_main) summed into out_main and [n_main, n_main+n_tail) into out_tail
+ * (the loss sums that follow a gradient in a slab row). */
+int mava_slab_reduce2_f32(const float* slab, int n_slab, long slab_stride, int n_main,
+                          float* out_main, int n_tail, float* out_tail, int accumulate,
+                          mava_stream_t s);
+
 /* ---- networks: mava/networks.py:39-58 (MLPTorso [128,128] relu), :88-124
  *      (DiscreteActionHead), :172-207 (FeedForwardActor / FeedForwardValueNet).
  * Flat parameter layout [W1(din,128) | b1 | W2(128,128) | b2 | W3(128,n_out) | b3], kernels
@@ -111,6 +117,22 @@ int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_i
                              const float* old_value, const float* targets, const int32_t* idx,
                              long idx_base, int Rb, int A, float clip_eps, float vf_coef,
                              float* slab, long slab_stride, int n_slab, mava_stream_t s);
+
+/* ---- synthetic RWARE-shaped environment (measurement stand-in for the third-party Jumanji
+ *      RobotWarehouse stepped at mava/systems/ppo/ff_mappo.py:88).  Wrapper semantics follow
+ *      mava/wrappers/observation.py:41-53, jumanji.py:53-59,128-143, auto_reset_wrapper.py:88-101
+ *      and episode_metrics.py:78-111.  One call = one vectorised env.step (or reset when is_reset).
+ * state: step_count (E,A) i32, run_return/ep_return (E) f32, run_length/ep_length (E) i32.
+ * outputs: agents_view (E,A,A+O), global_state (E,gs_tiles,A*O) with gs_tiles in {1,A},
+ * action_mask (E,A,n_actions) u8, obs_step_count (E,A) i32; transition: reward (E,A) f32,
+ * done (E,A) u8, info_return (E) f32, info_length (E) i32, info_terminal (E) u8. */
+int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int time_limit,
+                          uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
+                          int32_t* step_count, float* run_return, int32_t* run_length,
+                          float* ep_return, int32_t* ep_length, float* agents_view,
+                          float* global_state, uint8_t* action_mask, int32_t* obs_step_count,
+                          float* reward, uint8_t* done, float* info_return, int32_t* info_length,
+                          uint8_t* info_terminal, mava_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "mava_clip_adam": [vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, f32, f32, i32, i32, i32,
                        f32, f32, f32, vp, f32, f32, vp, vp],
     "mava_slab_reduce_f32": [vp, i32, lng, i32, i32, vp, vp],
+    "mava_slab_reduce2_f32": [vp, i32, lng, i32, vp, i32, vp, i32, vp],
     "mava_mlp_param_count": [i32, i32],
     "mava_mlp_forward_f32": [vp, i32, i32, vp, i32, i32, vp, vp],
     "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, u32, i32,
@@ -46,6 +47,7 @@ _SIGNATURES = {
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
+    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, u64, u32, u32, i32] + [vp] * 15,
 }
 _RESTYPES = {"mava_last_error": C.c_char_p}
 

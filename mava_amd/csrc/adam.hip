@@ -178,6 +178,45 @@ extern "C" int mava_clip_adam(float* p, const float* g, float* m, float* v, int3
   return MAVA_OK;
 }
 
+namespace {
+// Same reduction with the slab row split in two destinations: columns [0, n_main) go to out_main
+// and columns [n_main, n_main + n_tail) to out_tail (the loss sums that follow the gradient).
+__global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ slab, int n_slab,
+                                                           long slab_stride, int n_main, int n_tail,
+                                                           int accumulate, float* __restrict__ out_main,
+                                                           float* __restrict__ out_tail) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_main + n_tail) return;
+  float acc = 0.0f;
+  int b = 0;
+  for (; b + 4 <= n_slab; b += 4) {
+    const float a0 = slab[(long)(b + 0) * slab_stride + i];
+    const float a1 = slab[(long)(b + 1) * slab_stride + i];
+    const float a2 = slab[(long)(b + 2) * slab_stride + i];
+    const float a3 = slab[(long)(b + 3) * slab_stride + i];
+    acc = (((acc + a0) + a1) + a2) + a3;
+  }
+  for (; b < n_slab; ++b) acc += slab[(long)b * slab_stride + i];
+  float* dst = (i < n_main) ? (out_main + i) : (out_tail + (i - n_main));
+  *dst = accumulate ? (*dst + acc) : acc;
+}
+
+}  // namespace
+
+extern "C" int mava_slab_reduce2_f32(const float* slab, int n_slab, long slab_stride, int n_main,
+                                     float* out_main, int n_tail, float* out_tail, int accumulate,
+                                     hipStream_t s) {
+  MAVA_ARG_CHECK(n_main >= 0 && n_tail >= 0 && n_slab >= 0 && slab_stride >= n_main + n_tail, 0,
+                 "mava_slab_reduce2_f32: bad shape");
+  if (n_main + n_tail == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(slab && (n_main == 0 || out_main) && (n_tail == 0 || out_tail), 1,
+                 "mava_slab_reduce2_f32: null pointer argument");
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(mava_cdiv(n_main + n_tail, 256)), dim3(256), 0, s, slab,
+                     n_slab, slab_stride, n_main, n_tail, accumulate, out_main, out_tail);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
 extern "C" int mava_slab_reduce_f32(const float* slab, int n_slab, long slab_stride, int n,
                                     int accumulate, float* out, hipStream_t s) {
   MAVA_ARG_CHECK(n >= 0 && n_slab >= 0 && slab_stride >= n, 0,

@@ -1,0 +1,153 @@
+"""Synthetic RWARE-shaped vectorised environment.
+
+Stands in for `environments.make(config, add_global_state=...)` (mava/utils/make_env.py:215-240):
+Jumanji's RobotWarehouse is third-party JAX code that is not available, so observations, masks,
+rewards and dones are generated with RWARE's shapes and statistics by mava_synth_rware_step while
+the wrapper semantics the learner records (agent ids, global state, auto-reset, episode metrics)
+are reproduced.  The object follows the MarlEnv protocol (mava/types.py:34-108) in a natively
+BATCHED form: `reset`/`step` act on all `num_envs` environments of one (device, update-batch)
+replica at once, and `step_into` writes straight into trajectory slots owned by the learner.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, NamedTuple, Optional, Tuple
+
+import torch
+
+from .._lib import check, lib, ptr, stream_ptr
+from ..types import Observation, ObservationGlobalState, TimeStep
+
+
+class SynthState(NamedTuple):
+    step_count: torch.Tensor  # (E, A) i32
+    run_return: torch.Tensor  # (E,) f32   running_count_episode_return
+    run_length: torch.Tensor  # (E,) i32
+    ep_return: torch.Tensor  # (E,) f32   episode_return (last finished)
+    ep_length: torch.Tensor  # (E,) i32
+    t: torch.Tensor  # () i64 host-side step counter of this replica's stream
+
+
+class ObsSpec(NamedTuple):
+    agents_view: Tuple[int, ...]
+    action_mask: Tuple[int, ...]
+    global_state: Optional[Tuple[int, ...]]
+    step_count: Tuple[int, ...]
+
+
+class SyntheticRware:
+    # all agents of an env receive the same global_state row (mava/wrappers/jumanji.py:53-59)
+    global_state_shared = True
+
+    def __init__(self, num_envs: int, num_agents: int, obs_dim: int = 66, num_actions: int = 5, time_limit: int = 500,
+                 add_global_state: bool = False, add_agent_id: bool = True, seed: int = 42, env_offset: int = 0,
+                 tile_global_state: bool = False, device: Optional[torch.device] = None):
+        if not add_agent_id:
+            raise NotImplementedError("the synthetic generator always prepends the agent one-hot id (add_agent_id=True)")
+        self.num_envs, self.num_agents = int(num_envs), int(num_agents)
+        self.raw_obs_dim, self.action_dim, self.time_limit = int(obs_dim), int(num_actions), int(time_limit)
+        self.add_global_state = add_global_state
+        self.seed, self.env_offset = int(seed), int(env_offset)
+        self.gs_tiles = self.num_agents if tile_global_state else 1
+        self.global_state_shared = not tile_global_state
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def clone(self, env_offset: int, num_envs: Optional[int] = None) -> "SyntheticRware":
+        """Same environment family on a disjoint range of global env ids (one per replica / rank)."""
+        return SyntheticRware(num_envs or self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.time_limit,
+                              self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device)
+
+    # ---- specs ----------------------------------------------------------------------------
+    @property
+    def obs_dim(self) -> int:
+        return self.num_agents + self.raw_obs_dim
+
+    @property
+    def state_dim(self) -> int:
+        return self.num_agents * self.raw_obs_dim
+
+    def observation_spec(self) -> ObsSpec:
+        A = self.num_agents
+        return ObsSpec((A, self.obs_dim), (A, self.action_dim), (A, self.state_dim) if self.add_global_state else None, (A,))
+
+    def alloc_state(self) -> SynthState:
+        E, A, d = self.num_envs, self.num_agents, self.device
+        return SynthState(torch.zeros((E, A), dtype=torch.int32, device=d), torch.zeros(E, device=d),
+                          torch.zeros(E, dtype=torch.int32, device=d), torch.zeros(E, device=d),
+                          torch.zeros(E, dtype=torch.int32, device=d), torch.zeros((), dtype=torch.int64))
+
+    def alloc_obs(self) -> Dict[str, torch.Tensor]:
+        E, A, d = self.num_envs, self.num_agents, self.device
+        return {
+            "agents_view": torch.empty((E, A, self.obs_dim), device=d),
+            "global_state": torch.empty((E, self.gs_tiles, self.state_dim), device=d),
+            "action_mask": torch.empty((E, A, self.action_dim), dtype=torch.uint8, device=d),
+            "step_count": torch.empty((E, A), dtype=torch.int32, device=d),
+        }
+
+    # ---- kernel call ----------------------------------------------------------------------
+    def step_into(self, state: SynthState, t: int, obs: Dict[str, torch.Tensor], reward=None, done=None, info_return=None,
+                  info_length=None, info_terminal=None, is_reset: bool = False, env_offset: Optional[int] = None) -> None:
+        """One vectorised step (or reset) writing the next observation into `obs` and the transition
+        into the given (E, A) / (E,) slots.  `t` is the replica's global step index (Philox counter)."""
+        off = self.env_offset if env_offset is None else env_offset
+        check(
+            lib().mava_synth_rware_step(self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.gs_tiles,
+                                        self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, off & 0xFFFFFFFF,
+                                        int(is_reset), ptr(state.step_count), ptr(state.run_return), ptr(state.run_length),
+                                        ptr(state.ep_return), ptr(state.ep_length), ptr(obs["agents_view"]),
+                                        ptr(obs["global_state"]), ptr(obs["action_mask"]), ptr(obs["step_count"]),
+                                        ptr(reward), ptr(done), ptr(info_return), ptr(info_length), ptr(info_terminal),
+                                        stream_ptr()),
+            "mava_synth_rware_step",
+        )
+
+    # ---- MarlEnv-style batched API (allocating; the learner uses step_into) -----------------
+    def _observation(self, obs: Dict[str, torch.Tensor]):
+        mask = obs["action_mask"].bool()
+        if self.add_global_state:
+            gs = obs["global_state"]
+            gs = gs.expand(-1, self.num_agents, -1) if self.gs_tiles == 1 else gs
+            return ObservationGlobalState(obs["agents_view"], mask, gs, obs["step_count"])
+        return Observation(obs["agents_view"], mask, obs["step_count"])
+
+    def reset(self, key: Any = None) -> Tuple[SynthState, TimeStep]:
+        state, obs = self.alloc_state(), self.alloc_obs()
+        self.step_into(state, 0, obs, is_reset=True)
+        E, A, d = self.num_envs, self.num_agents, self.device
+        extras = {"episode_metrics": {"episode_return": torch.zeros(E, device=d),
+                                      "episode_length": torch.zeros(E, dtype=torch.int32, device=d),
+                                      "is_terminal_step": torch.zeros(E, dtype=torch.bool, device=d)}}
+        ts = TimeStep(torch.zeros(E, dtype=torch.int8, device=d), torch.zeros((E, A), device=d),
+                      torch.ones((E, A), device=d), self._observation(obs), extras)
+        return state, ts
+
+    def step(self, state: SynthState, action: torch.Tensor) -> Tuple[SynthState, TimeStep]:
+        E, A, d = self.num_envs, self.num_agents, self.device
+        obs = self.alloc_obs()
+        reward = torch.empty((E, A), device=d)
+        done = torch.empty((E, A), dtype=torch.uint8, device=d)
+        ir = torch.empty(E, device=d)
+        il = torch.empty(E, dtype=torch.int32, device=d)
+        it = torch.empty(E, dtype=torch.uint8, device=d)
+        t = int(state.t) + 1
+        self.step_into(state, t, obs, reward, done, ir, il, it)
+        state = state._replace(t=torch.tensor(t, dtype=torch.int64))
+        last = it.bool()
+        extras = {"episode_metrics": {"episode_return": ir, "episode_length": il, "is_terminal_step": last}}
+        step_type = torch.where(last, 2, 1).to(torch.int8)
+        ts = TimeStep(step_type, reward, 1.0 - done.float(), self._observation(obs), extras)
+        return state, ts
+
+
+def make(config, add_global_state: bool = False, device=None, env_offset: int = 0):
+    """Counterpart of mava/utils/make_env.py:215-240 for the synthetic stand-in: returns
+    (train_env, eval_env) sized by config.arch.num_envs / config.arch.num_eval_episodes."""
+    tc = config.env.scenario.task_config
+    syn = config.env.get("synthetic", {"obs_dim": 66, "num_actions": 5})
+    kw = dict(num_agents=int(tc.num_agents), obs_dim=int(syn["obs_dim"]), num_actions=int(syn["num_actions"]),
+              time_limit=int(config.env.kwargs.get("time_limit", 500)), add_global_state=add_global_state,
+              add_agent_id=bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id),
+              seed=int(config.system.seed), device=device)
+    train = SyntheticRware(num_envs=int(config.arch.num_envs), env_offset=env_offset, **kw)
+    evale = SyntheticRware(num_envs=int(config.arch.num_eval_episodes), env_offset=env_offset + (1 << 30), **kw)
+    return train, evale

@@ -1,0 +1,340 @@
+"""Feed-forward PPO learner (ff_ippo / ff_mappo) behind Mava's LearnerFn contract.
+
+Reference: mava/systems/ppo/ff_mappo.py:45-330 (get_learner_fn: _env_step, _calculate_gae,
+_update_epoch, _update_minibatch, learner_fn) and :333-432 (learner_setup); ff_ippo.py is the same
+file with a decentralised critic.  The XLA program that `jax.pmap(learn)` compiles
+is replaced by hand-written gfx950 kernels (libmavahip.so) launched from this module:
+
+    per update:  T x { policy_step -> env.step }         (rollout, time-major trajectory in HBM)
+                 critic forward on the last observation    (bootstrap value)
+                 GAE reverse scan                          (mava_gae_f32)
+                 K epochs x M minibatches x {adv stats, actor grad, critic grad, slab reduce,
+                                             [RCCL all-reduce], clip+Adam}
+
+Data layout (per GPU; U = update_batch_size replicas share parameters, ff_mappo.py:417-426):
+    params / grads / Adam moments : flat f32 [actor | critic] (+4 loss scalars after the grads)
+    trajectory, per replica       : time-major, (T+1, E, A, .) for observations (slot T is the
+                                    bootstrap observation and becomes slot 0 of the next rollout),
+                                    (T, E, A) for action / value / reward / log_prob / done
+    shuffle                       : an int32 permutation of T*E row ids; minibatches are slices of
+                                    it and rows are gathered inside the gradient kernels.
+One process drives one GPU; with world_size > 1 the env axis is sharded over ranks and the flat
+gradient is summed with one all-reduce per minibatch (ff_mappo.py:224-238 pmean "device").
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .networks import DiscreteActionHead, FeedForwardActor, FeedForwardValueNet, MLPTorso
+from .types import (AdamState, ExperimentOutput, LearnerState, Observation, ObservationGlobalState, OptStates, Params,
+                    TimeStep)
+
+NUM_CU = 256  # MI355X compute units: one persistent gradient block per CU
+
+
+def _dist_info() -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _Replica:
+    """Trajectory + env buffers of one update-batch replica (the vmapped axis of ff_mappo.py:319)."""
+
+    def __init__(self, env, T: int, n_upd: int, critic_uses_state: bool, device):
+        E, A = env.num_envs, env.num_agents
+        self.env = env
+        self.state = env.alloc_state()
+        d = device
+        self.agents_view = torch.empty((T + 1, E, A, env.obs_dim), device=d)
+        self.global_state = torch.empty((T + 1, E, env.gs_tiles, env.state_dim), device=d)
+        self.action_mask = torch.empty((T + 1, E, A, env.action_dim), dtype=torch.uint8, device=d)
+        self.step_count = torch.empty((T + 1, E, A), dtype=torch.int32, device=d)
+        self.action = torch.empty((T, E, A), dtype=torch.int32, device=d)
+        self.value = torch.empty((T, E, A), device=d)
+        self.reward = torch.empty((T, E, A), device=d)
+        self.log_prob = torch.empty((T, E, A), device=d)
+        self.done = torch.empty((T, E, A), dtype=torch.uint8, device=d)
+        self.last_val = torch.empty((E, A), device=d)
+        self.adv = torch.empty((T, E, A), device=d)
+        self.tgt = torch.empty((T, E, A), device=d)
+        # episode metrics of every update of one learn() call: (N_upd, T, E)
+        self.info_return = torch.zeros((n_upd, T, E), device=d)
+        self.info_length = torch.zeros((n_upd, T, E), dtype=torch.int32, device=d)
+        self.info_terminal = torch.zeros((n_upd, T, E), dtype=torch.uint8, device=d)
+        self.last_reward = torch.zeros((E, A), device=d)
+        self.last_done = torch.zeros((E, A), dtype=torch.uint8, device=d)
+
+    def obs_slot(self, t: int) -> Dict[str, torch.Tensor]:
+        return {"agents_view": self.agents_view[t], "global_state": self.global_state[t],
+                "action_mask": self.action_mask[t], "step_count": self.step_count[t]}
+
+
+class FFLearner:
+    def __init__(self, env, config, centralised_critic: bool, device: Optional[torch.device] = None):
+        self.config = config
+        self.centralised = centralised_critic
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rank, self.world = _dist_info()
+        s, arch = config.system, config.arch
+        self.E, self.U, self.T = int(arch.num_envs), int(s.update_batch_size), int(s.rollout_length)
+        self.K, self.M = int(s.ppo_epochs), int(s.num_minibatches)
+        if (self.T * self.E) % self.M:
+            raise ValueError("rollout_length * num_envs must be divisible by num_minibatches (ff_mappo.py:277-279)")
+        self.n_upd = int(s.get("num_updates_per_eval", 1))
+        # one env object per replica; global env ids are disjoint over (rank, replica)
+        self.reps: List[_Replica] = []
+        if env.num_envs != self.E:
+            raise ValueError(f"env.num_envs={env.num_envs} != arch.num_envs={self.E}")
+        if centralised_critic and not getattr(env, "add_global_state", False):
+            raise ValueError("Global state must be provided to the centralised critic.")  # networks.py:196-197
+        for u in range(self.U):
+            rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
+            self.reps.append(_Replica(rep_env, self.T, self.n_upd, centralised_critic, self.device))
+        env0 = self.reps[0].env
+        self.A, self.nA = env0.num_agents, env0.action_dim
+        config.system.num_agents = self.A  # ff_mappo.py:341
+        self.Oa = env0.obs_dim
+        if centralised_critic:
+            self.Oc = env0.state_dim
+            self.critic_share = self.A if env0.global_state_shared else 1
+        else:
+            self.Oc = self.Oa
+            self.critic_share = 1
+
+        # networks (ff_mappo.py:347-354) - hydra.utils.instantiate is replaced by direct construction
+        net = config.network
+        a_torso = MLPTorso(**{k: v for k, v in net.actor_network.pre_torso.items() if k != "_target_"})
+        c_torso = MLPTorso(**{k: v for k, v in net.critic_network.pre_torso.items() if k != "_target_"})
+        self.actor_network = FeedForwardActor(a_torso, DiscreteActionHead(self.nA), self.Oa)
+        self.critic_network = FeedForwardValueNet(c_torso, centralised_critic, self.Oc)
+        self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
+        self.P = self.Pa + self.Pc
+
+        d = self.device
+        self.p = torch.zeros(self.P, device=d)
+        self.m = torch.zeros(self.P, device=d)
+        self.v = torch.zeros(self.P, device=d)
+        self.count = torch.zeros(2, dtype=torch.int32, device=d)
+        self.g = torch.zeros(self.P + 4, device=d)  # [actor grad | critic grad | actor_loss, entropy, value_loss, pad]
+        self.seg_off = [0, self.Pa, self.P]
+        self.seg_lr = [float(s.actor_lr), float(s.critic_lr)]
+
+        self.Rb = self.T * self.E // self.M  # env rows per minibatch
+        ntiles = (self.Rb * self.A + 31) // 32
+        self.n_slab = max(1, min(NUM_CU, ntiles))
+        self.slab_a = torch.zeros((self.n_slab, self.Pa + 2), device=d)
+        self.slab_c = torch.zeros((self.n_slab, self.Pc + 2), device=d)
+        self.stats = torch.zeros((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
+        self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
+        self.perm_gen = torch.Generator(device=d)
+        self.t_global = 0  # env steps taken per env so far (Philox step counter)
+        self.seed = int(s.seed)
+
+    # ------------------------------------------------------------------------------------ setup
+    def init_params(self, actor_seed: int, critic_seed: int) -> None:
+        self.p[: self.Pa].copy_(self.actor_network.init_flat(actor_seed))
+        self.p[self.Pa :].copy_(self.critic_network.init_flat(critic_seed))
+        self.m.zero_()
+        self.v.zero_()
+        self.count.zero_()
+
+    def reset_envs(self) -> None:
+        for rep in self.reps:
+            rep.env.step_into(rep.state, 0, rep.obs_slot(0), is_reset=True)
+        self.t_global = 0
+        self.perm_gen.manual_seed(self.seed)
+
+    # ---------------------------------------------------------------------------- state <-> views
+    def _params_tree(self) -> Params:
+        lead = (1, self.U)
+        return Params(self.actor_network.tree(self.p[: self.Pa], lead), self.critic_network.tree(self.p[self.Pa :], lead))
+
+    def _opt_tree(self) -> OptStates:
+        lead = (1, self.U)
+        out = []
+        for i, (net, sl) in enumerate(((self.actor_network, slice(0, self.Pa)), (self.critic_network, slice(self.Pa, self.P)))):
+            out.append(AdamState(self.count[i].expand(1, self.U), net.tree(self.m[sl], lead), net.tree(self.v[sl], lead)))
+        return OptStates(*out)
+
+    def _timestep(self, slot: int) -> TimeStep:
+        def stack(f):
+            return torch.stack([f(r) for r in self.reps], 0).unsqueeze(0)  # (1, U, E, ...)
+
+        av = stack(lambda r: r.agents_view[slot])
+        mask = stack(lambda r: r.action_mask[slot]).bool()
+        sc = stack(lambda r: r.step_count[slot])
+        if self.centralised:
+            gs = stack(lambda r: r.global_state[slot].expand(-1, self.A, -1) if r.env.gs_tiles == 1 else r.global_state[slot])
+            obs: Any = ObservationGlobalState(av, mask, gs, sc)
+        else:
+            obs = Observation(av, mask, sc)
+        done = stack(lambda r: r.last_done[:, 0]).bool()
+        step_type = torch.where(done, 2, 1).to(torch.int8)
+        reward = stack(lambda r: r.last_reward)
+        n = max(self.n_upd - 1, 0)
+        extras = {"episode_metrics": {
+            "episode_return": stack(lambda r: r.info_return[n, -1]),
+            "episode_length": stack(lambda r: r.info_length[n, -1]),
+            "is_terminal_step": stack(lambda r: r.info_terminal[n, -1]).bool()}}
+        return TimeStep(step_type, reward, 1.0 - stack(lambda r: r.last_done).float(), obs, extras)
+
+    def learner_state(self) -> LearnerState:
+        key = torch.tensor([[[self.seed, self.t_global]] * self.U], dtype=torch.int64)  # (1, U, 2) host tensor
+        env_state = {
+            "step_count": torch.stack([r.state.step_count for r in self.reps], 0).unsqueeze(0),
+            "running_count_episode_return": torch.stack([r.state.run_return for r in self.reps], 0).unsqueeze(0),
+            "running_count_episode_length": torch.stack([r.state.run_length for r in self.reps], 0).unsqueeze(0),
+            "episode_return": torch.stack([r.state.ep_return for r in self.reps], 0).unsqueeze(0),
+            "episode_length": torch.stack([r.state.ep_length for r in self.reps], 0).unsqueeze(0),
+        }
+        return LearnerState(self._params_tree(), self._opt_tree(), key, env_state, self._timestep(0))
+
+    def adopt(self, state: LearnerState) -> None:
+        """Make the device buffers equal to `state` (no-op for leaves that already alias them), so that
+        learn() is a function of its argument like the reference's pure learner_fn."""
+        pa = state.params.actor_params["params"]["torso"]["Dense_0"]["kernel"]
+        if pa.data_ptr() != self.p.data_ptr():
+            self.actor_network.flat_from_tree(state.params.actor_params, self.p[: self.Pa])
+            self.critic_network.flat_from_tree(state.params.critic_params, self.p[self.Pa :])
+            for i, (net, sl, st) in enumerate(((self.actor_network, slice(0, self.Pa), state.opt_states.actor_opt_state),
+                                               (self.critic_network, slice(self.Pa, self.P), state.opt_states.critic_opt_state))):
+                net.flat_from_tree(st.mu, self.m[sl])
+                net.flat_from_tree(st.nu, self.v[sl])
+                self.count[i] = int(st.count.reshape(-1)[0])
+
+    # ------------------------------------------------------------------------------------ update
+    def _rollout(self, n: int) -> None:
+        """ff_mappo.py:76-106: T acting steps, recording the time-major trajectory in place."""
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        EA = self.E * self.A
+        for t in range(self.T):
+            step = self.t_global + t
+            for u, rep in enumerate(self.reps):
+                av = rep.agents_view[t].view(EA, self.Oa)
+                if self.centralised:
+                    cx = rep.global_state[t].view(-1, self.Oc)
+                else:
+                    cx = av
+                ops.policy_step(pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
+                                critic_share=self.critic_share, critic_rows=EA, seed=self.seed, step=step,
+                                row_offset=(self.rank * self.U + u) * EA,
+                                out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)))
+                last = t == self.T - 1
+                rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
+                                  rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t])
+                if last:
+                    rep.last_reward.copy_(rep.reward[t])
+                    rep.last_done.copy_(rep.done[t])
+        self.t_global += self.T
+
+    def _bootstrap_and_gae(self) -> None:
+        """ff_mappo.py:109-139."""
+        s = self.config.system
+        pc = self.p[self.Pa :]
+        EA = self.E * self.A
+        for rep in self.reps:
+            cx = rep.global_state[self.T].view(-1, self.Oc) if self.centralised else rep.agents_view[self.T].view(EA, self.Oa)
+            lv = ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share)
+            rep.last_val.view(-1).copy_(lv.view(-1))
+            ops.gae(rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
+                    rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
+                    out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
+
+    def _minibatch(self, n: int, k: int, mb: int, perm: Optional[torch.Tensor]) -> None:
+        """ff_mappo.py:144-266 for minibatch `mb` of epoch `k`."""
+        s = self.config.system
+        T, E, A = self.T, self.E, self.A
+        TEA = T * E * A
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        idx = None if perm is None else perm[mb * self.Rb : (mb + 1) * self.Rb]
+        base = mb * self.Rb
+        for u, rep in enumerate(self.reps):
+            acc = u > 0
+            av = rep.agents_view[:T].view(TEA, self.Oa)
+            ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
+            ops.ppo_actor_grad(pa, av, rep.action_mask[:T].view(TEA, self.nA), rep.action.view(TEA), rep.log_prob.view(TEA),
+                               rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA, float(s.clip_eps),
+                               float(s.ent_coef), self.slab_a)
+            cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
+            ops.ppo_critic_grad(pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA), idx, base, self.Rb, A,
+                                float(s.clip_eps), float(s.vf_coef), self.slab_c)
+            ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=acc)
+            ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)  # RCCL over xGMI; pmean "device" of ff_mappo.py:228-238
+        ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
+                      grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
+                      decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
+                      num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
+                      ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
+
+    def _epoch_permutation(self) -> torch.Tensor:
+        """ff_mappo.py:272-273: one permutation of the T*E rows per epoch, identical on every replica
+        and rank (the reference hands the same PRNG key to all of them, :417-426)."""
+        return torch.randperm(self.T * self.E, generator=self.perm_gen, device=self.device).to(torch.int32)
+
+    def update(self, n: int, permutations: Optional[List[torch.Tensor]] = None) -> None:
+        self._rollout(n)
+        self._bootstrap_and_gae()
+        for k in range(self.K):
+            perm = permutations[k] if permutations is not None else self._epoch_permutation()
+            for mb in range(self.M):
+                self._minibatch(n, k, mb, perm)
+        # the bootstrap observation becomes the first observation of the next rollout
+        for rep in self.reps:
+            rep.agents_view[0].copy_(rep.agents_view[self.T])
+            rep.global_state[0].copy_(rep.global_state[self.T])
+            rep.action_mask[0].copy_(rep.action_mask[self.T])
+            rep.step_count[0].copy_(rep.step_count[self.T])
+
+    def learn(self, learner_state: LearnerState) -> ExperimentOutput:
+        """LearnerFn (mava/types.py:154): num_updates_per_eval updates, asynchronous on the current
+        stream - the caller synchronises before reading the clock (ff_mappo.py:497-498)."""
+        self.adopt(learner_state)
+        for n in range(self.n_upd):
+            self.update(n)
+        U = self.U
+        episode_metrics = {
+            "episode_return": torch.stack([r.info_return for r in self.reps], 1).unsqueeze(0),  # (1,N,U,T,E)
+            "episode_length": torch.stack([r.info_length for r in self.reps], 1).unsqueeze(0),
+            "is_terminal_step": torch.stack([r.info_terminal for r in self.reps], 1).unsqueeze(0).bool(),
+        }
+        tm = self.train_metrics.unsqueeze(1).expand(self.n_upd, U, self.K, self.M, 4).unsqueeze(0)  # (1,N,U,K,M,4)
+        train_metrics = {"total_loss": tm[..., 0], "value_loss": tm[..., 1], "actor_loss": tm[..., 2], "entropy": tm[..., 3]}
+        return ExperimentOutput(self.learner_state(), episode_metrics, train_metrics)
+
+
+def learner_setup(env, keys, config, centralised_critic: bool, device=None):
+    """Counterpart of learner_setup (ff_mappo.py:333-432): returns (learn, actor_network,
+    init_learner_state).  `keys` = (key, actor_net_key, critic_net_key) integer seeds."""
+    key, actor_key, critic_key = (int(k) for k in keys)
+    learner = FFLearner(env, config, centralised_critic, device)
+    learner.seed = key
+    learner.init_params(actor_key, critic_key)
+    if learner.world > 1:
+        import torch.distributed as dist
+
+        dist.broadcast(learner.p, src=0)
+    learner.reset_envs()
+    learn = learner.learn
+    learn.learner = learner  # type: ignore[attr-defined]
+    return learn, learner.actor_network, learner.learner_state()
+
+
+def get_final_step_metrics(metrics: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], bool]:
+    """mava/wrappers/episode_metrics.py:114-132."""
+    metrics = dict(metrics)
+    is_final = metrics.pop("is_terminal_step").bool()
+    has_final = bool(is_final.any())
+    if not has_final:
+        return {k: torch.zeros_like(v) for k, v in metrics.items()}, False
+    return {k: v[is_final] for k, v in metrics.items()}, True

@@ -1,0 +1,179 @@
+"""Network definitions behind the reference's module names (mava/networks.py:39-58 MLPTorso,
+:88-124 DiscreteActionHead, :172-183 FeedForwardActor, :186-207 FeedForwardValueNet).
+
+A network here is (a) a flat float32 parameter vector in the kernel layout
+[W1(din,128) | b1 | W2(128,128) | b2 | W3(128,n_out) | b3] and (b) a Flax-shaped tree of VIEWS into
+that vector, so `Params.actor_params["params"]["torso"]["Dense_0"]["kernel"]` is what a Mava user
+expects while the kernels see one contiguous buffer.  `apply` runs the HIP forward kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .distributions import Categorical
+from .types import Observation, ObservationGlobalState
+
+HIDDEN = 128
+
+
+class MLPTorso:
+    """mava/networks.py:39-58.  Only the configuration the fused kernels implement is accepted."""
+
+    def __init__(self, layer_sizes: Sequence[int] = (128, 128), activation: str = "relu", use_layer_norm: bool = False,
+                 **_: Any):
+        self.layer_sizes = list(layer_sizes)
+        self.activation = activation
+        self.use_layer_norm = use_layer_norm
+        if self.layer_sizes != [HIDDEN, HIDDEN] or activation != "relu" or use_layer_norm:
+            raise NotImplementedError(
+                "mava_amd's fused MLP kernels implement layer_sizes=[128,128], activation=relu, "
+                f"use_layer_norm=False (network/mlp.yaml defaults); got {self.layer_sizes}, {activation}, "
+                f"layer_norm={use_layer_norm}"
+            )
+
+
+class DiscreteActionHead:
+    """mava/networks.py:88-124."""
+
+    def __init__(self, action_dim: int, **_: Any):
+        self.action_dim = int(action_dim)
+
+
+def _orthogonal_(w: torch.Tensor, scale: float, gen: torch.Generator) -> None:
+    """flax.linen.initializers.orthogonal(scale) semantics (QR of a normal matrix, sign-fixed) on the
+    host; the bit stream differs from JAX's PRNG (init parity is not a goal)."""
+    rows, cols = w.shape
+    a = torch.randn((max(rows, cols), min(rows, cols)), generator=gen, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r))
+    if rows < cols:
+        q = q.T
+    w.copy_((scale * q[:rows, :cols]).to(w.dtype))
+
+
+def mlp_segments(din: int, n_out: int):
+    """[(name path, shape, offset)] in kernel order."""
+    segs, off = [], 0
+    for path, shape in (
+        (("Dense_0", "kernel"), (din, HIDDEN)),
+        (("Dense_0", "bias"), (HIDDEN,)),
+        (("Dense_1", "kernel"), (HIDDEN, HIDDEN)),
+        (("Dense_1", "bias"), (HIDDEN,)),
+        (("head", "kernel"), (HIDDEN, n_out)),
+        (("head", "bias"), (n_out,)),
+    ):
+        n = math.prod(shape)
+        segs.append((path, shape, off))
+        off += n
+    return segs, off
+
+
+class _FeedForwardNet:
+    head_scale = 1.0
+    head_parent = None  # name of the sub-module holding the head Dense
+
+    def __init__(self, din: int, n_out: int):
+        self.din, self.n_out = int(din), int(n_out)
+        self.segments, self.num_params = mlp_segments(self.din, self.n_out)
+
+    # -- parameters -------------------------------------------------------------------------
+    def init_flat(self, seed: int, device=None) -> torch.Tensor:
+        """networks.py:54 orthogonal(sqrt 2) torso kernels, zero biases; head scale per subclass."""
+        gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        flat = torch.zeros(self.num_params, dtype=torch.float32)
+        for path, shape, off in self.segments:
+            if path[1] == "kernel":
+                scale = self.head_scale if path[0] == "head" else math.sqrt(2.0)
+                _orthogonal_(flat[off : off + math.prod(shape)].view(shape), scale, gen)
+        return flat.to(device) if device is not None else flat
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        """Flax-shaped tree of views into `flat` (optionally with broadcast leading dims)."""
+        def view(shape, off):
+            v = flat[off : off + math.prod(shape)].view(shape)
+            return v.expand(*lead, *shape) if lead else v
+
+        by = {path: view(shape, off) for path, shape, off in self.segments}
+        torso = {
+            "Dense_0": {"kernel": by[("Dense_0", "kernel")], "bias": by[("Dense_0", "bias")]},
+            "Dense_1": {"kernel": by[("Dense_1", "kernel")], "bias": by[("Dense_1", "bias")]},
+        }
+        head = {"kernel": by[("head", "kernel")], "bias": by[("head", "bias")]}
+        return {"params": self._assemble(torso, head)}
+
+    def flat_from_tree(self, tree: Dict[str, Any], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Inverse of `tree` (accepts leaves with extra leading broadcast dims: takes index 0)."""
+        torso, head = self._disassemble(tree["params"])
+        leaves = {
+            ("Dense_0", "kernel"): torso["Dense_0"]["kernel"], ("Dense_0", "bias"): torso["Dense_0"]["bias"],
+            ("Dense_1", "kernel"): torso["Dense_1"]["kernel"], ("Dense_1", "bias"): torso["Dense_1"]["bias"],
+            ("head", "kernel"): head["kernel"], ("head", "bias"): head["bias"],
+        }
+        if out is None:
+            any_leaf = leaves[("head", "bias")]
+            out = torch.empty(self.num_params, dtype=torch.float32, device=any_leaf.device)
+        for path, shape, off in self.segments:
+            leaf = leaves[path]
+            while leaf.dim() > len(shape):
+                leaf = leaf[0]
+            out[off : off + math.prod(shape)].view(shape).copy_(leaf)
+        return out
+
+
+class FeedForwardActor(_FeedForwardNet):
+    """mava/networks.py:172-183 with DiscreteActionHead (:88-124): head Dense init orthogonal(0.01)."""
+
+    head_scale = 0.01
+
+    def __init__(self, torso: MLPTorso, action_head: DiscreteActionHead, obs_dim: int):
+        super().__init__(obs_dim, action_head.action_dim)
+        self.torso, self.action_head = torso, action_head
+
+    def _assemble(self, torso, head):
+        return {"torso": torso, "action_head": {"Dense_0": head}}
+
+    def _disassemble(self, p):
+        return p["torso"], p["action_head"]["Dense_0"]
+
+    def apply(self, params: Any, observation) -> Categorical:
+        """actor_network.apply(params, observation) -> distribution (mava/evaluator.py:182-183)."""
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        av = observation.agents_view
+        lead = av.shape[:-1]
+        x = av.reshape(-1, av.shape[-1]).contiguous().float()
+        logits = ops.mlp_forward(flat.contiguous(), self.din, self.n_out, x)
+        mask = observation.action_mask
+        return Categorical(logits.view(*lead, self.n_out), None if mask is None else mask.reshape(*lead, self.n_out))
+
+
+class FeedForwardValueNet(_FeedForwardNet):
+    """mava/networks.py:186-207: head Dense(1) init orthogonal(1.0); centralised => global_state."""
+
+    head_scale = 1.0
+
+    def __init__(self, torso: MLPTorso, centralised_critic: bool, input_dim: int):
+        super().__init__(input_dim, 1)
+        self.torso, self.centralised_critic = torso, centralised_critic
+
+    def _assemble(self, torso, head):
+        return {"torso": torso, "Dense_0": head}
+
+    def _disassemble(self, p):
+        return p["torso"], p["Dense_0"]
+
+    def apply(self, params: Any, observation) -> torch.Tensor:
+        if self.centralised_critic:
+            if not isinstance(observation, ObservationGlobalState):
+                # mava/networks.py:196-197
+                raise ValueError("Global state must be provided to the centralised critic.")
+            x = observation.global_state
+        else:
+            x = observation.agents_view
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        lead = x.shape[:-1]
+        v = ops.mlp_forward(flat.contiguous(), self.din, 1, x.reshape(-1, x.shape[-1]).contiguous().float())
+        return v.view(*lead)

@@ -267,3 +267,18 @@ def ppo_critic_grad(params, critic_input, x_share: int, old_value, targets, idx,
                                        slab.shape[0], stream_ptr()),
         "mava_ppo_critic_grad_f32",
     )
+
+
+def slab_reduce2(slab: torch.Tensor, n_main: int, out_main: torch.Tensor, n_tail: int, out_tail: torch.Tensor,
+                 accumulate: bool = False) -> None:
+    """Sum slab rows: columns [0,n_main) -> out_main, [n_main, n_main+n_tail) -> out_tail."""
+    _req(slab, torch.float32, "slab")
+    _req(out_main, torch.float32, "out_main")
+    _req(out_tail, torch.float32, "out_tail")
+    if slab.dim() != 2 or slab.shape[1] < n_main + n_tail or out_main.numel() < n_main or out_tail.numel() < n_tail:
+        raise ValueError("slab_reduce2: inconsistent sizes")
+    check(
+        lib().mava_slab_reduce2_f32(ptr(slab), slab.shape[0], slab.shape[1], n_main, ptr(out_main), n_tail, ptr(out_tail),
+                                    int(accumulate), stream_ptr()),
+        "mava_slab_reduce2_f32",
+    )

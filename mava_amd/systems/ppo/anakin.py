@@ -1,0 +1,72 @@
+"""Experiment driver shared by the four PPO systems: the host loop of
+mava/systems/ppo/ff_mappo.py:435-553 (run_experiment) - train for num_updates_per_eval updates,
+synchronise, report steps_per_second with the reference's own accounting, evaluate, repeat.
+Logging is reduced to the metric names of SURVEY.md §5.5 on stdout/JSON; checkpointing uses
+mava_amd/utils/checkpointing.py.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import time
+from typing import Any, Callable, Dict, Optional
+
+import torch
+
+from ...config import Config, check_total_timesteps
+from ...learner import get_final_step_metrics
+
+
+def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable, add_global_state: bool,
+                   log: Optional[Callable[[Dict[str, Any]], None]] = None) -> float:
+    config = copy.deepcopy(_config)
+    import torch.distributed as dist
+
+    n_devices = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if n_devices > 1 else 0
+    env, eval_env = make_env(config, add_global_state=add_global_state)
+
+    seed = int(config.system.seed)
+    key, key_e, actor_key, critic_key = seed, seed + 1, seed + 2, seed + 3  # stands in for random.split(PRNGKey(seed), 4)
+
+    config = check_total_timesteps(config, n_devices)
+    assert config.system.num_updates > config.arch.num_evaluation, (
+        "Number of updates per evaluation must be less than total number of updates."  # ff_mappo.py:462-464
+    )
+    config.system.num_updates_per_eval = config.system.num_updates // config.arch.num_evaluation
+    steps_per_rollout = (n_devices * config.system.num_updates_per_eval * config.system.rollout_length
+                         * config.system.update_batch_size * config.arch.num_envs)  # ff_mappo.py:468-474
+
+    learn, actor_network, learner_state = learner_setup(env, (key, actor_key, critic_key), config)
+
+    from ...evaluator import get_eval_fn, make_ff_eval_act_fn
+
+    evaluator = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, config), config, absolute_metric=False)
+
+    def emit(rec: Dict[str, Any]) -> None:
+        if rank == 0:
+            (log or (lambda r: print(json.dumps(r), flush=True)))(rec)
+
+    eval_return = 0.0
+    for eval_step in range(int(config.arch.num_evaluation)):
+        torch.cuda.synchronize()
+        start = time.time()
+        out = learn(learner_state)
+        torch.cuda.synchronize()  # jax.block_until_ready, ff_mappo.py:498
+        elapsed = time.time() - start
+        t = int(steps_per_rollout * (eval_step + 1))
+        ep_metrics, ep_completed = get_final_step_metrics(out.episode_metrics)
+        rec: Dict[str, Any] = {"timestep": t, "steps_per_second": steps_per_rollout / elapsed}
+        if ep_completed:
+            rec["episode_return"] = float(ep_metrics["episode_return"].float().mean())
+            rec["episode_length"] = float(ep_metrics["episode_length"].float().mean())
+        for k, v in out.train_metrics.items():
+            rec[k] = float(v.float().mean())  # TRAIN metrics are mean-reduced (mava/utils/logger.py:72-74)
+        # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:513 vs :535)
+        trained_params = learner_state.params.actor_params
+        eval_metrics = evaluator(trained_params, key_e + eval_step)
+        eval_return = float(eval_metrics["episode_return"].float().mean())
+        rec["eval_episode_return"] = eval_return
+        emit(rec)
+        learner_state = out.learner_state
+    return eval_return

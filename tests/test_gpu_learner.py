@@ -1,0 +1,145 @@
+"""End-to-end GPU parity: the HIP learner (through the Mava-shaped boundary) against the NumPy
+whole-update oracle on identical inputs (same parameters, same Philox action noise, same epoch
+permutations), plus bit-exact parity of the synthetic environment generator."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+from oracle.ppo_loop import OracleLearner
+from oracle.synth_env import SynthRware
+from tests.conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(system, scenario_agents, E, T, K, M, U, extra=()):
+    from mava_amd.config import compose
+
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}", *extra])
+    cfg.env.scenario.task_config.num_agents = scenario_agents
+    return cfg
+
+
+def test_synthetic_env_bit_exact(dev):
+    from mava_amd.envs import SyntheticRware
+
+    E, A, O, nA = 37, 3, 21, 5
+    env = SyntheticRware(E, A, O, nA, time_limit=6, add_global_state=True, seed=1234, env_offset=1000, device=dev)
+    ora = SynthRware(E, A, O, nA, time_limit=6, seed=1234, env_offset=1000)
+    state, ts = env.reset()
+    o = ora.reset(0)
+    assert np.array_equal(ts.observation.agents_view.cpu().numpy(), o["agents_view"])
+    assert np.array_equal(ts.observation.global_state.cpu().numpy(), np.repeat(o["global_state"], A, 1))
+    assert np.array_equal(ts.observation.action_mask.cpu().numpy(), o["action_mask"])
+    n_term = 0
+    for t in range(1, 40):
+        state, ts = env.step(state, torch.zeros((E, A), dtype=torch.int32, device=dev))
+        o, r, d, info = ora.step(t)
+        assert np.array_equal(ts.observation.agents_view.cpu().numpy(), o["agents_view"]), t
+        assert np.array_equal(ts.observation.action_mask.cpu().numpy(), o["action_mask"]), t
+        assert np.array_equal(ts.observation.step_count.cpu().numpy(), o["step_count"]), t
+        assert np.array_equal(ts.reward.cpu().numpy(), r), t
+        assert np.array_equal(ts.last().cpu().numpy(), d[:, 0]), t
+        m = ts.extras["episode_metrics"]
+        assert np.array_equal(m["episode_return"].cpu().numpy(), info["episode_return"]), t
+        assert np.array_equal(m["episode_length"].cpu().numpy(), info["episode_length"]), t
+        assert np.array_equal(m["is_terminal_step"].cpu().numpy(), info["is_terminal_step"]), t
+        n_term += int(d[:, 0].sum())
+    assert n_term >= E * 5  # the time limit of 6 forces resets
+    # agent ids are one-hot, global state is the concatenation of the raw views
+    av = ts.observation.agents_view.cpu().numpy()
+    assert np.array_equal(av[:, :, :A], np.broadcast_to(np.eye(A, dtype=np.float32), (E, A, A)))
+    assert np.array_equal(ts.observation.global_state.cpu().numpy()[:, 0], av[:, :, A:].reshape(E, A * O))
+
+
+@pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])
+def test_learner_update_matches_oracle(dev, system, U):
+    from mava_amd import envs
+    from mava_amd.systems.ppo import ff_ippo, ff_mappo
+
+    E, A, O, nA, T, K, M = 8, 2, 10, 5, 16, 2, 2
+    cfg = _cfg(system, A, E, T, K, M, U)
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": nA}
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr = 1e-3
+    cfg.system.critic_lr = 2e-3
+    central = system == "ff_mappo"
+    mod = ff_mappo if central else ff_ippo
+    env, _ = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+
+    # make the networks non-trivial (head scale 0.01 would give a near-uniform policy)
+    rng = np.random.default_rng(0)
+    fa = po.mlp_flatten(po.init_mlp(rng, A + O, nA, 1.0)).astype(np.float32)
+    fc = po.mlp_flatten(po.init_mlp(rng, (A * O) if central else (A + O), 1, 1.0)).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+
+    ora = OracleLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=U, D=1, centralised=central, seed=42, actor_lr=1e-3,
+                        critic_lr=2e-3)
+    ora.set_params(fa, fc)
+
+    for n in range(2):
+        perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[0][u]
+            assert np.array_equal(rep.action.cpu().numpy(), tr["action"]), "sampled actions differ"
+            assert np.array_equal(rep.done.cpu().numpy().astype(bool), tr["done"])
+            assert_close(rep.value.cpu().numpy(), tr["value"], 1e-5, "values")
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-5, "log_probs")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], 1e-5, "advantages")  # north_star 1e-5
+            assert_close(rep.tgt.cpu().numpy(), tr["tgt"], 1e-5, "targets")
+            assert np.array_equal(rep.info_terminal[n].cpu().numpy().astype(bool), tr["term"])
+            assert np.array_equal(rep.info_length[n].cpu().numpy(), tr["len"])
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 1e-3, "actor update")
+        assert_close(L.p[L.Pa :].cpu().numpy() - fc, ora.pc - fc, 1e-3, "critic update")
+        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+    assert L.count.cpu().tolist() == [2 * K * M, 2 * K * M]
+
+
+def test_learn_contract_shapes(dev):
+    """learn(LearnerState) -> ExperimentOutput with the reference's leaf layout."""
+    from mava_amd import envs
+    from mava_amd.learner import get_final_step_metrics
+    from mava_amd.systems.ppo import ff_mappo
+
+    E, A, T, K, M, U, N = 16, 4, 8, 2, 2, 2, 3
+    cfg = _cfg("ff_mappo", A, E, T, K, M, U)
+    cfg.system.num_updates_per_eval = N
+    cfg.env.kwargs.time_limit = 5
+    env, eval_env = envs.make(cfg, add_global_state=True, device=dev)
+    learn, actor_network, state = ff_mappo.learner_setup(env, (1, 2, 3), cfg, device=dev)
+    assert cfg.system.num_agents == A
+    k0 = state.params.actor_params["params"]["torso"]["Dense_0"]["kernel"]
+    assert k0.shape == (1, U, A + 66, 128)
+    assert state.params.critic_params["params"]["Dense_0"]["kernel"].shape == (1, U, 128, 1)
+    assert state.timestep.observation.global_state.shape == (1, U, E, A, A * 66)
+    before = k0[:, 0].clone()  # unreplicate_batch_dim
+    out = learn(state)
+    torch.cuda.synchronize()
+    assert out.episode_metrics["episode_return"].shape == (1, N, U, T, E)
+    assert out.train_metrics["total_loss"].shape == (1, N, U, K, M)
+    for k in ("total_loss", "value_loss", "actor_loss", "entropy"):
+        assert torch.isfinite(out.train_metrics[k]).all()
+    after = out.learner_state.params.actor_params["params"]["torso"]["Dense_0"]["kernel"][0, 0]  # unreplicate_n_dims
+    assert not torch.equal(before[0], after)
+    assert int(out.learner_state.opt_states.actor_opt_state.count[0, 0]) == N * K * M
+    fm, done = get_final_step_metrics(out.episode_metrics)
+    assert done and (fm["episode_length"] <= 5).all() and (fm["episode_length"] >= 1).all()
+    # entropy of a freshly initialised policy (head scale 0.01) is close to log(n_legal)
+    ent = float(out.train_metrics["entropy"][0, 0, 0, 0, 0])
+    assert 1.3 < ent < np.log(5) + 1e-3
+    # evaluator seam
+    from mava_amd.evaluator import get_eval_fn, make_ff_eval_act_fn
+
+    ev = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
+    m = ev(out.learner_state.params.actor_params, 0)
+    assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes

@@ -136,6 +136,18 @@ class FFLearner:
         self.perm_gen = torch.Generator(device=d)
         self.t_global = 0  # env steps taken per env so far (Philox step counter)
         self.seed = int(s.seed)
+        self.timers: Optional[Dict[str, list]] = None  # bench.py: name -> [(start_event, end_event)]
+
+    def _timed(self, name: str, fn, *args, **kwargs):
+        """Run one kernel launch, optionally bracketed by HIP events on the launch stream."""
+        if self.timers is None:
+            return fn(*args, **kwargs)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn(*args, **kwargs)
+        b.record()
+        self.timers.setdefault(name, []).append((a, b))
+        return out
 
     # ------------------------------------------------------------------------------------ setup
     def init_params(self, actor_seed: int, critic_seed: int) -> None:
@@ -222,13 +234,13 @@ class FFLearner:
                     cx = rep.global_state[t].view(-1, self.Oc)
                 else:
                     cx = av
-                ops.policy_step(pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
+                self._timed("policy_step", ops.policy_step, pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
                                 critic_share=self.critic_share, critic_rows=EA, seed=self.seed, step=step,
                                 row_offset=(self.rank * self.U + u) * EA,
                                 out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)))
                 last = t == self.T - 1
-                rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
-                                  rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t])
+                self._timed("env_step", rep.env.step_into, rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
+                            rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t])
                 if last:
                     rep.last_reward.copy_(rep.reward[t])
                     rep.last_done.copy_(rep.done[t])
@@ -243,9 +255,9 @@ class FFLearner:
             cx = rep.global_state[self.T].view(-1, self.Oc) if self.centralised else rep.agents_view[self.T].view(EA, self.Oa)
             lv = ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share)
             rep.last_val.view(-1).copy_(lv.view(-1))
-            ops.gae(rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
-                    rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
-                    out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
+            self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
+                        rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
+                        out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
 
     def _minibatch(self, n: int, k: int, mb: int, perm: Optional[torch.Tensor]) -> None:
         """ff_mappo.py:144-266 for minibatch `mb` of epoch `k`."""
@@ -259,19 +271,19 @@ class FFLearner:
             acc = u > 0
             av = rep.agents_view[:T].view(TEA, self.Oa)
             ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
-            ops.ppo_actor_grad(pa, av, rep.action_mask[:T].view(TEA, self.nA), rep.action.view(TEA), rep.log_prob.view(TEA),
-                               rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA, float(s.clip_eps),
-                               float(s.ent_coef), self.slab_a)
+            self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA), rep.action.view(TEA),
+                        rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA,
+                        float(s.clip_eps), float(s.ent_coef), self.slab_a)
             cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
-            ops.ppo_critic_grad(pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA), idx, base, self.Rb, A,
-                                float(s.clip_eps), float(s.vf_coef), self.slab_c)
+            self._timed("critic_grad", ops.ppo_critic_grad, pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA),
+                        idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c)
             ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=acc)
             ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
         if self.world > 1:
             import torch.distributed as dist
 
             dist.all_reduce(self.g, op=dist.ReduceOp.SUM)  # RCCL over xGMI; pmean "device" of ff_mappo.py:228-238
-        ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
+        self._timed("clip_adam", ops.clip_adam, self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
                       num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
@@ -325,8 +337,10 @@ def learner_setup(env, keys, config, centralised_critic: bool, device=None):
 
         dist.broadcast(learner.p, src=0)
     learner.reset_envs()
-    learn = learner.learn
-    learn.learner = learner  # type: ignore[attr-defined]
+    def learn(learner_state: LearnerState) -> ExperimentOutput:
+        return learner.learn(learner_state)
+
+    learn.learner = learner  # type: ignore[attr-defined]  (handle for tests / bench)
     return learn, learner.actor_network, learner.learner_state()
 
 

@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mava_hip.h declares (no compute)."""
+import os
+import re
+
+from mava_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "mava_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mava_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in mava_hip.h but not exported by libmavahip.so"
+    assert lib.mava_abi_version() == 1
+
+
+def test_python_binding_matches_header():
+    assert _header_symbols() == _lib.declared_symbols()
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.lib()
+    # rejected on the host before any launch
+    rc = lib.mava_gae_f32(None, None, None, None, None, -1, 4, 0.99, 0.95, None, None, None)
+    assert rc <= -1000
+    assert b"negative shape" in lib.mava_last_error()
+    assert lib.mava_mlp_param_count(70, 5) == 26245 and lib.mava_mlp_param_count(264, 1) == 50561
+    rc = lib.mava_mlp_forward_f32(None, 70, 99, None, 1, 8, None, None)
+    assert rc <= -1000
+
+
+def test_product_path_refuses_cpu_tensors():
+    import pytest
+    import torch
+
+    from mava_amd import ops
+
+    r = torch.zeros(4, 8)
+    with pytest.raises(_lib.MavaHipError):
+        ops.gae(r, r.clone(), torch.zeros(4, 8, dtype=torch.uint8), torch.zeros(8), 0.99, 0.95)

@@ -1,0 +1,189 @@
+"""CPU: the oracle against (a) published known answers where they exist (Philox), (b) analytic
+properties of the reference algorithm, (c) an independent torch-autograd restatement, and (d) the
+committed golden fixtures (regression pin; parity with Mava itself is unpinned, see oracle headers)."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from oracle import philox, ppo_oracle as po, torch_ref
+from oracle.synth_env import SynthRware
+from tests.conftest import assert_close
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for c, k, want in kat:
+        got = tuple(int(x) for x in philox.philox4x32_10(*c, *k))
+        assert got == want
+
+
+@settings(max_examples=25, deadline=None)
+@given(T=st.integers(1, 40), N=st.integers(1, 9), seed=st.integers(0, 10_000))
+def test_gae_properties(T, N, seed):
+    rng = np.random.default_rng(seed)
+    r, v, lv = rng.standard_normal((T, N)), rng.standard_normal((T, N)), rng.standard_normal(N)
+    z = np.zeros((T, N), bool)
+    adv, tgt = po.gae(r, v, z, lv, 1.0, 1.0)  # lambda=gamma=1, no dones: telescoping sum
+    assert np.allclose(adv, np.cumsum(r[::-1], 0)[::-1] + lv - v)
+    adv, tgt = po.gae(r, v, ~z, lv, 0.99, 0.95)  # all done: adv = r - V, target = r
+    assert np.allclose(adv, r - v) and np.allclose(tgt, r)
+    # recurrent masking == feed-forward masking with the done array shifted by one step
+    d = rng.random((T, N)) < 0.3
+    ld = rng.random(N) < 0.3
+    a_rec, _ = po.gae(r, v, d, lv, 0.99, 0.95, last_done=ld)
+    a_ff, _ = po.gae(r, v, np.concatenate([d[1:], ld[None]], 0), lv, 0.99, 0.95)
+    assert np.allclose(a_rec, a_ff)
+    # chunked affine composition == sequential scan (the GPU kernel's algebra)
+    c = 0.99 * 0.95 * (1 - d)
+    delta = r + 0.99 * np.concatenate([v[1:], lv[None]], 0) * (1 - d) - v
+    L = max(1, T // 3)
+    a_in = np.zeros(N)
+    out = np.zeros((T, N))
+    for hi in range(T, 0, -L):
+        lo = max(0, hi - L)
+        S, P = np.zeros((hi - lo, N)), np.zeros((hi - lo, N))
+        a, p = np.zeros(N), np.ones(N)
+        for t in range(hi - 1, lo - 1, -1):
+            a = delta[t] + c[t] * a
+            p = c[t] * p
+            S[t - lo], P[t - lo] = a, p
+        out[lo:hi] = S + P * a_in
+        a_in = out[lo]
+    assert np.allclose(out, po.gae(r, v, d, lv, 0.99, 0.95)[0])
+
+
+def test_gae_f32_vs_f64_tolerance_form():
+    """a pure elementwise rtol of 1e-5 is unattainable even for sequential f32; the stated
+    form |a-b| <= rtol*|b| + rtol*rms(b) holds."""
+    rng = np.random.default_rng(0)
+    r, v = rng.standard_normal((128, 4096)).astype(np.float32), rng.standard_normal((128, 4096)).astype(np.float32)
+    d = rng.random((128, 4096)) < 1 / 500
+    lv = rng.standard_normal(4096).astype(np.float32)
+    a64, _ = po.gae(r, v, d, lv, 0.99, 0.95)
+    a32, _ = po.gae(r, v, d, lv, 0.99, 0.95, dtype=np.float32)
+    assert_close(a32, a64, 1e-5, "f32 vs f64")
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_manual_gradients_match_autograd(seed):
+    rng = np.random.default_rng(seed)
+    R, din, nA = 200, 17, 6
+    p = po.mlp_flatten(po.init_mlp(rng, din, nA, 1.0)) + rng.standard_normal(po.mlp_param_count(din, nA)) * 0.05
+    obs = rng.standard_normal((R, din))
+    mask = rng.random((R, nA)) > 0.3
+    act = rng.integers(0, nA, R)
+    mask[np.arange(R), act] = True
+    lsm = po.log_softmax(po.masked_logits(po.mlp_forward(po.mlp_unflatten(p, din, nA), obs), mask))
+    olp = lsm[np.arange(R), act] + rng.standard_normal(R) * 0.25
+    adv = rng.standard_normal(R)
+    a = po.actor_loss_and_grad(p, din, nA, obs, mask, act, olp, adv, 0.2, 0.01)
+    b = torch_ref.actor_grad(p, din, nA, obs, mask, act, olp, adv, 0.2, 0.01)
+    assert abs(a[0] - b[0]) < 1e-12 and abs(a[1] - b[1]) < 1e-12 and abs(a[2] - b[2]) < 1e-12
+    assert np.abs(a[3] - b[3]).max() < 1e-12
+    pc = po.mlp_flatten(po.init_mlp(rng, din, 1, 1.0))
+    v = po.mlp_forward(po.mlp_unflatten(pc, din, 1), obs)[:, 0]
+    ov, tg = v + rng.standard_normal(R) * 0.2, v + rng.standard_normal(R)
+    a = po.critic_loss_and_grad(pc, din, obs, ov, tg, 0.2, 0.5)
+    b = torch_ref.critic_grad(pc, din, obs, ov, tg, 0.2, 0.5)
+    assert abs(a[0] - b[0]) < 1e-12 and np.abs(a[2] - b[2]).max() < 1e-12
+
+
+def test_actor_gradient_finite_difference():
+    rng = np.random.default_rng(5)
+    R, din, nA = 40, 6, 4
+    p = po.mlp_flatten(po.init_mlp(rng, din, nA, 1.0))
+    obs, mask = rng.standard_normal((R, din)), np.ones((R, nA), bool)
+    act = rng.integers(0, nA, R)
+    olp, adv = -1.3 + rng.standard_normal(R) * 0.1, rng.standard_normal(R)
+    f = lambda q: po.actor_loss_and_grad(q, din, nA, obs, mask, act, olp, adv, 0.2, 0.01)[0]
+    g = po.actor_loss_and_grad(p, din, nA, obs, mask, act, olp, adv, 0.2, 0.01)[3]
+    for i in rng.integers(0, p.size, 12):
+        e = np.zeros_like(p)
+        e[i] = 1e-6
+        fd = (f(p + e) - f(p - e)) / 2e-6
+        assert abs(fd - g[i]) < 1e-6 + 1e-4 * abs(g[i]), (i, fd, g[i])
+
+
+def test_clip_adam_semantics():
+    rng = np.random.default_rng(1)
+    p, g = rng.standard_normal(50), rng.standard_normal(50) * 10
+    pn, m, v, c = po.clip_adam(p, g, np.zeros(50), np.zeros(50), 0, 1e-3, 0.5)
+    gc = g / np.sqrt((g * g).sum()) * 0.5  # clipped to norm 0.5
+    assert np.allclose(m, 0.1 * gc) and np.allclose(v, 0.001 * gc * gc) and c == 1
+    # first step of Adam moves by lr * g/(|g| + eps*...) ~ lr * sign(g)
+    assert np.allclose(pn, p - 1e-3 * gc / (np.abs(gc) + 1e-5))
+    assert po.learning_rate(1.0, 17, True, 4, 2, 10) == 1.0 - (17 // 8) / 10
+    assert po.learning_rate(1.0, 17, False, 4, 2, 10) == 1.0
+
+
+def test_minibatch_rows_follow_reference_reshape():
+    perm = np.random.default_rng(0).permutation(24)
+    got = np.stack([po.minibatch_rows(perm, 3, i) for i in range(3)])
+    assert np.array_equal(got, perm.reshape(3, -1))  # jnp.reshape(x, (num_minibatches, -1, ...)), ff_mappo.py:277-280
+
+
+def test_synth_env_semantics():
+    env = SynthRware(9, 3, 21, 5, time_limit=4, seed=7)
+    o = env.reset(0)
+    assert o["agents_view"].shape == (9, 3, 24) and o["global_state"].shape == (9, 1, 63)
+    assert np.array_equal(o["agents_view"][:, :, :3], np.broadcast_to(np.eye(3, dtype=np.float32), (9, 3, 3)))
+    assert np.array_equal(o["global_state"][:, 0], o["agents_view"][:, :, 3:].reshape(9, 63))
+    lens = []
+    for t in range(1, 30):
+        o, r, d, info = env.step(t)
+        assert (r == r[:, :1]).all() and (d == d[:, :1]).all()  # team reward / shared done
+        assert ((o["step_count"] == 0) | ~d).all()  # auto-reset: terminal step returns a reset observation
+        lens.append(info["episode_length"][info["is_terminal_step"]])
+    lens = np.concatenate(lens)
+    assert lens.max() <= 4 and lens.min() >= 1
+
+
+# ------------------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", ["gae_small.npz", "gae_cfg1.npz"])
+def test_golden_gae(name):
+    z = np.load(os.path.join(G, name))
+    adv, tgt = po.gae(z["reward"], z["value"], z["done"], z["last_val"], float(z["gamma"]), float(z["gae_lambda"]))
+    assert np.array_equal(adv, z["adv"]) and np.array_equal(tgt, z["tgt"])
+    adv, tgt = po.gae(z["reward"], z["value"], z["done"], z["last_val"], float(z["gamma"]), float(z["gae_lambda"]),
+                      last_done=z["last_done"])
+    assert np.array_equal(adv, z["adv_rec"]) and np.array_equal(tgt, z["tgt_rec"])
+
+
+@pytest.mark.parametrize("name", ["loss_small.npz", "loss_rware.npz"])
+def test_golden_losses(name):
+    z = np.load(os.path.join(G, name))
+    O, A, nA = int(z["O"]), int(z["A"]), int(z["nA"])
+    ta, la, ent, ga = po.actor_loss_and_grad(z["actor_params"].astype(np.float64), O + A, nA, z["obs"].astype(np.float64),
+                                             z["mask"], z["action"], z["old_log_prob"].astype(np.float64),
+                                             z["adv"].astype(np.float64), 0.2, 0.01)
+    assert np.allclose(ga, z["actor_grad"], rtol=0, atol=1e-14) and abs(la - float(z["actor_loss"])) < 1e-14
+    tc, vl, gc = po.critic_loss_and_grad(z["critic_params"].astype(np.float64), A * O, z["global_state"].astype(np.float64),
+                                         z["old_value"].astype(np.float64), z["targets"].astype(np.float64), 0.2, 0.5)
+    assert np.allclose(gc, z["critic_grad"], rtol=0, atol=1e-14) and abs(vl - float(z["value_loss"])) < 1e-14
+    b = torch_ref.critic_grad(z["critic_params"].astype(np.float64), A * O, z["global_state"].astype(np.float64),
+                              z["old_value"].astype(np.float64), z["targets"].astype(np.float64), 0.2, 0.5)
+    assert np.abs(b[2] - z["critic_grad"]).max() < 1e-12
+
+
+def test_golden_adam_and_rng():
+    z = np.load(os.path.join(G, "adam.npz"))
+    for tag in ("small", "big"):
+        pn, mn, vn, c = po.clip_adam(z["p"], z[f"g_{tag}"], z["m"], z["v"], int(z["count"]), float(z["lr"]), float(z["max_norm"]))
+        assert np.array_equal(pn, z[f"p_{tag}"]) and np.array_equal(mn, z[f"m_{tag}"]) and np.array_equal(vn, z[f"v_{tag}"])
+    z = np.load(os.path.join(G, "rng.npz"))
+    assert np.array_equal(philox.policy_uniforms(0x1234ABCD5678EF01, 77, 16, 5, row_offset=1000), z["policy_uniforms"])
+    env = SynthRware(6, 3, 21, 5, time_limit=4, seed=1234, env_offset=10)
+    assert np.array_equal(env.reset(0)["agents_view"], z["av0"])
+    for t in range(1, 7):
+        o, r, d, info = env.step(t)
+        assert np.array_equal(o["agents_view"], z["av"][t - 1]) and np.array_equal(r, z["reward"][t - 1])
+        assert np.array_equal(info["episode_length"], z["ep_length"][t - 1])

@@ -32,6 +32,33 @@ def _ev_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  os.cpu_count() reports the
+    whole host and oversubscribes a quota-limited container by an order of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,8 +114,11 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc}")
+    for i in range(args.warmup):
         L.update(0)
+        torch.cuda.synchronize()
+        log(f"warmup update {i} done")
     if not args.no_kernel_timers:
         L.timers = {}
     barrier()
@@ -106,6 +136,7 @@ def main() -> None:
 
     env_steps = world * args.steps * T * U * E  # ff_mappo.py:468-474
     value = env_steps / elapsed
+    log(f"timed region: {args.steps} updates in {elapsed:.3f} s -> {value:,.0f} env-steps/s")
 
     out = {
         "metric": "env-steps/sec (whole node), ff_mappo RWARE tiny-4ag",
@@ -160,7 +191,8 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_loop
 
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
+        log(f"cpu baseline on {cores} usable cores (os.cpu_count()={os.cpu_count()}) ...")
         res = cpu_loop.run(E=args.cpu_envs, A=A, O=L.Oa - A, nA=L.nA, T=T, K=K, M=M, updates=64, warmup=1,
                            threads=cores, max_seconds=args.cpu_seconds)
         out["cpu_baseline"] = {
@@ -169,6 +201,7 @@ def main() -> None:
                       f"input distributions) at {args.cpu_envs} envs x {T} steps, {res['env_steps']} env-steps in "
                       f"{res['seconds']:.1f} s; substitute for Mava's JAX CPU path, which is not installable here",
         }
+        log(f"cpu baseline: {res['env_steps_per_sec']:,.0f} env-steps/s")
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import ops, parallel
 from .networks import DiscreteActionHead, FeedForwardActor, FeedForwardValueNet, MLPTorso
 from .types import (AdamState, ExperimentOutput, LearnerState, Observation, ObservationGlobalState, OptStates, Params,
                     TimeStep)
@@ -37,11 +37,7 @@ NUM_CU = 256  # MI355X compute units: one persistent gradient block per CU
 
 
 def _dist_info() -> Tuple[int, int]:
-    import torch.distributed as dist
-
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    return parallel.rank_world()
 
 
 class _Replica:
@@ -279,10 +275,7 @@ class FFLearner:
                         idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c)
             ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=acc)
             ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
-        if self.world > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)  # RCCL over xGMI; pmean "device" of ff_mappo.py:228-238
+        parallel.allreduce_sum_(self.g)  # RCCL over xGMI; pmean "device" of ff_mappo.py:228-238
         self._timed("clip_adam", ops.clip_adam, self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
@@ -332,10 +325,7 @@ def learner_setup(env, keys, config, centralised_critic: bool, device=None):
     learner = FFLearner(env, config, centralised_critic, device)
     learner.seed = key
     learner.init_params(actor_key, critic_key)
-    if learner.world > 1:
-        import torch.distributed as dist
-
-        dist.broadcast(learner.p, src=0)
+    parallel.broadcast_(learner.p, src=0)
     learner.reset_envs()
     def learn(learner_state: LearnerState) -> ExperimentOutput:
         return learner.learn(learner_state)

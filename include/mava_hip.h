@@ -95,7 +95,7 @@ int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions
  * epoch permutation) or idx_base + b when idx is NULL.  Each of the n_slab persistent blocks
  * writes one partial slab of slab_stride floats: [gradient in parameter layout | loss sums];
  * mava_slab_reduce_f32 sums the slabs in a fixed order.  All sums are already divided by the
- * minibatch element count Rb*A (the .mean() of the reference). */
+ * minibatch element count Rb*A (the .mean() of the reference).  Row arithmetic is 32-bit: TE*A < 2^31. */
 
 int mava_adv_stats_blocks(void); /* number of (sum, sumsq) f64 pairs mava_adv_stats_f64 writes */
 

@@ -28,6 +28,9 @@ CPP_SOURCES = ["api.cpp"]
 
 COMMON_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "..", "include")]
 HIP_FLAGS = [f"--offload-arch={ARCH}", "-ffp-contract=fast", "-Wno-unused-result"]
+# developer knobs: MAVA_HIPCC_EXTRA="-DMAVA_FAST_BUILD -DMAVA_STAMPS" builds a diagnostic library
+EXTRA_FLAGS = os.environ.get("MAVA_HIPCC_EXTRA", "").split()
+FLAG_STAMP = os.path.join(CSRC, ".build_flags")
 
 
 def _headers():
@@ -36,8 +39,14 @@ def _headers():
     return [h for h in hs if os.path.exists(h)]
 
 
+def _flags_changed() -> bool:
+    cur = " ".join(EXTRA_FLAGS)
+    old = open(FLAG_STAMP).read() if os.path.exists(FLAG_STAMP) else ""
+    return cur != old
+
+
 def _stale(src: str, obj: str) -> bool:
-    if not os.path.exists(obj):
+    if not os.path.exists(obj) or _flags_changed():
         return True
     t = os.path.getmtime(obj)
     deps = [src, os.path.abspath(__file__)] + _headers()
@@ -51,9 +60,7 @@ def _compile(src: str, verbose: bool) -> str:
         return obj
     cmd = [HIPCC, "-c", path, "-o", obj] + COMMON_FLAGS
     if src.endswith(".hip"):
-        cmd += HIP_FLAGS
-    else:
-        cmd += ["-x", "hip", f"--offload-arch={ARCH}"] if False else []
+        cmd += HIP_FLAGS + EXTRA_FLAGS
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -68,7 +75,10 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
     srcs = [s for s in HIP_SOURCES + CPP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
-    need_link = (not os.path.exists(OUT_LIB)) or any(
+    flags_changed = _flags_changed()
+    with open(FLAG_STAMP, "w") as f:
+        f.write(" ".join(EXTRA_FLAGS))
+    need_link = flags_changed or (not os.path.exists(OUT_LIB)) or any(
         os.path.getmtime(o) > os.path.getmtime(OUT_LIB) for o in objs
     )
     if need_link:

@@ -306,10 +306,22 @@ struct Categorical {
   float entropy;
 
   __device__ __forceinline__ void build(const float (&y)[NO], const uint8_t* mask, int no) {
+    uint32_t bits = 0xFFFFFFFFu;
+    if (mask != nullptr) {
+      bits = 0;
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        if (o < no && mask[o] != 0) bits |= (1u << o);
+    }
+    build_bits(y, bits, no);
+  }
+
+  // legality given as a bit per action
+  __device__ __forceinline__ void build_bits(const float (&y)[NO], uint32_t bits, int no) {
     float mx = -FLT_MAX;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-      const bool legal = (o < no) && (mask == nullptr || mask[o] != 0);
+      const bool legal = (o < no) && ((bits >> o) & 1u);
       z[o] = legal ? y[o] : -FLT_MAX;
       mx = fmaxf(mx, z[o]);
     }

@@ -47,21 +47,43 @@ struct TrainTask {
   float clip_eps, ent_coef, vf_coef;
   float* slab;
   long slab_stride;
+  unsigned long long* stamps;  // diagnostic builds only (-DMAVA_STAMPS): per-phase cycle sums of block 0
+};
+
+#ifdef MAVA_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                   \
+  do {                                                             \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                                 \
+    st_prev = st_now;                                              \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
+// LDS carve (floats) computed on the host per launch (din / NO dependent), checked against 160 KiB.
+struct TrainLdsLayout {
+  int h1t, h2t, dz2t, yp, dy, xs, misc, end;
+  int ldx;  // row stride of the staged x tile: 32*KT1 + 1 (odd => conflict-free column walks)
 };
 
 template <int NO>
-struct TrainLds {
-  static constexpr int TILE = MLP_H * LDT;
-  static constexpr int H1T = MlpLds<NO>::END;
-  static constexpr int H2T = H1T + TILE;
-  static constexpr int DZ2T = H2T + TILE;
-  static constexpr int DZ1T = DZ2T + TILE;  // doubles as YP[4][NO][32] (partial logits) until P4
-  static constexpr int DZ1T_SIZE = (TILE > 4 * NO * 32) ? TILE : 4 * NO * 32;
-  static constexpr int DY = DZ1T + DZ1T_SIZE;  // [NO][32]
-  static constexpr int ROWX = DY + NO * 32;    // 32 x int64
-  static constexpr int MISC = ROWX + 64;
-  static constexpr int END = MISC + 8;
-};
+TrainLdsLayout make_layout(int kt1) {
+  TrainLdsLayout L;
+  const int tile = MLP_H * LDT;
+  L.h1t = MlpLds<NO>::END;
+  L.h2t = L.h1t + tile;   // h2^T, later dz1^T (after the P4 sweeps, behind an extra barrier)
+  L.dz2t = L.h2t + tile;
+  L.yp = L.dz2t + tile;   // [4][NO][32] partial logits
+  L.dy = L.yp + 4 * NO * 32;
+  L.ldx = 32 * kt1 + 1;
+  L.xs = L.dy + NO * 32;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns
+  L.misc = L.xs + 32 * L.ldx + 32;
+  L.end = L.misc + 8;
+  return L;
+}
 
 // advantage statistics of one minibatch: partial (sum, sumsq) in f64 per block
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv,
@@ -92,71 +114,68 @@ __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict_
   }
 }
 
-// Layer-1 product for ONE 32-feature tile with a PD-deep register ring of operand prefetches
-// (one wave per SIMD: nothing else hides the L2 / HBM latency).
-template <int XV, int PD>
-__device__ __forceinline__ void l1_tile(const float* __restrict__ xrow, int din,
-                                        const float* __restrict__ wcol, int h, f32x16& z) {
-  constexpr int STEP = 2 * XV;
-  const int nfull = din / STEP;
-  float xb[PD][XV], wb[PD][XV];
-  auto load = [&](int c, float (&xo)[XV], float (&wo)[XV]) {
-    if (c < nfull) {
-      const int k0 = c * STEP + XV * h;
-      typename XVec<XV>::T xv = *reinterpret_cast<const typename XVec<XV>::T*>(xrow + k0);
-      const float* xs = reinterpret_cast<const float*>(&xv);
+// flat trajectory row (t*E+e)*A + a of agent-row q of the minibatch
+__device__ __forceinline__ long traj_row(const TrainTask& tk, long q, long R) {
+  const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));  // R < 2^31 is checked on the host
+  const uint32_t b = qc / (uint32_t)tk.A;
+  const uint32_t a = qc - b * (uint32_t)tk.A;
+  const long p = tk.idx ? (long)tk.idx[b] : tk.idx_base + (long)b;
+  return p * tk.A + a;
+}
+
+// Register-staged copy of one gathered 32-row x tile: 8 threads per row, thread l8 takes columns
+// l8, l8+8, ... (32-byte pieces per row per instruction; every 128-B line is fetched from HBM once and
+// the remaining pieces hit L2).  Plain dword loads with immediate offsets: no per-load address math, no
+// alignment requirement on the row stride.  Issued a whole tile ahead of its use (global -> registers
+// now, registers -> LDS after the consumers of the previous tile have passed their last barrier).
+template <int NR>
+__device__ __forceinline__ void stage_load(const float* __restrict__ xrow_l8, int din, int l8,
+                                           float (&xr)[NR]) {
+  // columns 8i..8i+7 are valid for every thread when i < din/8 (uniform scalar branch, no exec masking);
+  // at most one trailing group is partial
+  const int nfull = din >> 3;
 #pragma unroll
-      for (int m = 0; m < XV; ++m) {
-        xo[m] = xs[m];
-        wo[m] = wcol[(k0 + m) * MLP_H];
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < XV; ++m) { xo[m] = 0.f; wo[m] = 0.f; }
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < PD; ++u) load(u, xb[u], wb[u]);
-  for (int c0 = 0; c0 < nfull; c0 += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      if (c0 + u < nfull) {
-#pragma unroll
-        for (int m = 0; m < XV; ++m) z = MFMA32(wb[u][m], xb[u][m], z);
-      }
-      load(c0 + u + PD, xb[u], wb[u]);
-    }
+  for (int i = 0; i < NR; ++i) {
+    if (i < nfull) xr[i] = xrow_l8[8 * i];
+    else if (i == nfull && l8 + 8 * i < din) xr[i] = xrow_l8[8 * i];
+    else xr[i] = 0.0f;
   }
-  for (int k0 = nfull * STEP; k0 < din; k0 += 2) {
-    const int k = k0 + h;
-    const bool ok = k < din;
-    const int kc = ok ? k : (din - 1);
-    const float xv = ok ? xrow[kc] : 0.0f;
-    z = MFMA32(wcol[kc * MLP_H], xv, z);
+}
+template <int NR>
+__device__ __forceinline__ void stage_write(float* xs_row_l8, int din, int l8, const float (&xr)[NR]) {
+  const int nfull = din >> 3;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (i < nfull) xs_row_l8[8 * i] = xr[i];
+    else if (i == nfull && l8 + 8 * i < din) xs_row_l8[8 * i] = xr[i];
   }
 }
 
 template <int NO, int KT1, bool ACTOR>
-__global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
+__global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLdsLayout L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const W2s = lds + MlpLds<NO>::W2;
   float* const W3s = lds + MlpLds<NO>::W3;
-  float* const H1T = lds + TrainLds<NO>::H1T;
-  float* const H2T = lds + TrainLds<NO>::H2T;
-  float* const DZ2T = lds + TrainLds<NO>::DZ2T;
-  float* const DZ1T = lds + TrainLds<NO>::DZ1T;
-  float* const YP = DZ1T;
-  float* const DY = lds + TrainLds<NO>::DY;
-  long* const rowx = reinterpret_cast<long*>(lds + TrainLds<NO>::ROWX);
-  float* const misc = lds + TrainLds<NO>::MISC;
+  float* const H1T = lds + L.h1t;
+  float* const H2T = lds + L.h2t;
+  float* const DZ1T = H2T;  // alias, see barrier D'
+  float* const DZ2T = lds + L.dz2t;
+  float* const YP = lds + L.yp;
+  float* const DY = lds + L.dy;
+  float* const XS = lds + L.xs;
+  float* const misc = lds + L.misc;
+  const int ldx = L.ldx;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
+  const int srow = tid >> 3, l8 = tid & 7;  // staging role: row srow of the tile, 8 threads per row
   const int din = tk.din, no = tk.no;
   const long R = (long)tk.Rb * tk.A;
   const float invR = 1.0f / (float)R;
+  constexpr int NR = 4 * KT1;  // staged floats per thread (32*KT1 columns / 8 threads)
 
   mlp_fill_lds<NO>(lds, tk.params, din, no, 256);
+  for (int i = tid; i < 32 * ldx + 32; i += 256) XS[i] = 0.0f;  // zero padding columns stay zero
   if (ACTOR && tid == 0) {
     // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
     double s1 = 0.0, s2 = 0.0;
@@ -194,34 +213,144 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
   const float* const wcol1 = tk.params + 32 * w + j;  // W1[k][32w + j] = wcol1[k*128]
   const int fbase = 32 * w + 4 * h;                   // + (r&3) + 8*(r>>2)
 
-  const long ntiles = (R + 31) / 32;
-  for (long it = blockIdx.x; it < ntiles; it += gridDim.x) {
-    const long q = it * 32 + j;
-    const bool valid = q < R;
-    long fr = 0;
-    if (valid) {
-      const long b = q / tk.A;
-      const int a = (int)(q - b * tk.A);
-      const long p = tk.idx ? (long)tk.idx[b] : tk.idx_base + b;
-      fr = p * tk.A + a;
+  // per-row inputs of the loss (row j of the tile), prefetched one tile ahead
+  // NOTHING in the prefetch path may do arithmetic on a value it has just loaded: the compiler places the
+  // vmcnt wait at the first use, and vmcnt retires in order, so one early use exposes the whole HBM gather.
+  constexpr int NMB = ACTOR ? (NO + 3) / 4 : 1;  // raw mask bytes, 4 per register
+  struct RowIn {
+    int act;
+    float f0, f1;        // actor: old_logp, advantage ; critic: old_value, target
+    uint8_t mraw[4 * NMB];  // raw action-mask bytes (decoded in P3)
+  };
+  auto load_row = [&](long fr) {
+    RowIn ri;
+    if (ACTOR) {
+      ri.act = tk.action[fr];
+      ri.f0 = tk.old_logp[fr];
+      ri.f1 = tk.adv[fr];
+      const uint8_t* mk = tk.mask ? (tk.mask + fr * no) : nullptr;
+#pragma unroll
+      for (int o = 0; o < 4 * NMB; ++o) ri.mraw[o] = (mk != nullptr && o < no) ? mk[o] : (uint8_t)1;
+    } else {
+      ri.act = 0;
+      ri.f0 = tk.old_value[fr];
+      ri.f1 = tk.targets[fr];
+      ri.mraw[0] = 0;
     }
-    const long xr = fr / tk.xshare;
-    const float* xrow = tk.x + xr * din;
-    if (w == 0 && h == 0) rowx[j] = xr;
+    return ri;
+  };
+  // minibatch index gather, raw: returns idx[b] (or the identity) without touching it
+  auto gather_idx = [&](long q, uint32_t& b_out) -> int32_t {
+    const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));
+    b_out = qc / (uint32_t)tk.A;
+    return tk.idx ? tk.idx[b_out] : (int32_t)(tk.idx_base + (long)b_out);
+  };
+  auto row_of = [&](long q, int32_t p_raw) -> long {
+    const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));
+    const uint32_t a = qc % (uint32_t)tk.A;
+    return (long)p_raw * tk.A + a;
+  };
+  auto stage_issue = [&](long fr, float (&xr)[NR]) {
+    const uint32_t xrow_idx = (uint32_t)fr / (uint32_t)tk.xshare;  // 32-bit: TE*A < 2^31 is checked on the host
+    const float* xrow = tk.x + (long)xrow_idx * din + l8;
+    stage_load<NR>(xrow, din, l8, xr);
+  };
+  auto stage_commit = [&](const float (&xr)[NR]) { stage_write<NR>(XS + srow * ldx + l8, din, l8, xr); };
+
+  constexpr int RD = (2 * KT1 < 4) ? 2 * KT1 : 4;  // W1 operand ring depth (batches of 8 k-steps)
+  float wr[RD][8];
+  const float* const wcol1h = wcol1 + h * MLP_H;  // W1[k + h][32w + j] = wcol1h[k * 128]
+#pragma unroll
+  for (int d = 0; d < RD; ++d)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wr[d][s] = wcol1h[(16 * d + 2 * s) * MLP_H];
+
+  const long ntiles = (R + 31) / 32;
+  long it = blockIdx.x;
+  float xr[NR];
+  RowIn rin = {};
+  // trajectory rows of the NEXT tile for both thread roles (staging row srow / loss row j): the index
+  // gather runs one tile ahead of the loads that depend on it, two tiles ahead of the compute
+  int32_t ps_next = 0, pj_next = 0;  // RAW idx values of the next tile (staging row srow / loss row j)
+  if (it < ntiles) {
+    stage_issue(traj_row(tk, it * 32 + srow, R), xr);
+    rin = load_row(traj_row(tk, it * 32 + j, R));
+    stage_commit(xr);
+    const long itn0 = it + gridDim.x;
+    if (itn0 < ntiles) {
+      uint32_t bb;
+      ps_next = gather_idx(itn0 * 32 + srow, bb);
+      pj_next = gather_idx(itn0 * 32 + j, bb);
+    }
+  }
+  __syncthreads();
+
+  STAMP_DECL
+  for (; it < ntiles; it += gridDim.x) {
+    STAMP(9);
+    const bool valid = (it * 32 + j) < R;
+    const long itn = it + gridDim.x;
+    const bool have_next = itn < ntiles;
+    RowIn rnext = rin;
 
     // ---------------------------------------------------------------- P1: layer 1, tile w
     f32x16 h1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) h1[r] = lds[MlpLds<NO>::B1 + fbase + (r & 3) + 8 * (r >> 2)];
-    if (tk.xv == 4) l1_tile<4, 4>(xrow, din, wcol1, h, h1);
-    else if (tk.xv == 2) l1_tile<2, 6>(xrow, din, wcol1, h, h1);
-    else l1_tile<1, 8>(xrow, din, wcol1, h, h1);
+    {
+      // W1 operands stream from L2 through a shifting ring of RD batches of 8 k-steps (prefetch distance
+      // RD*512 MFMA cycles).  The refill index wraps, so when the loop ends the ring already holds
+      // batches 0..RD-1 for the next row tile.  x operands come from the staged LDS tile one batch ahead.
+      const float* xb = XS + j * ldx + h;  // x[row j][k + h]
+      constexpr int NB = 2 * KT1;          // batches of 8 k-steps (16 inputs)
+      float xc[8], xn[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xc[s] = xb[2 * s];
+#pragma unroll 1
+      for (int b = 0; b < NB; ++b) {
+        const int bn = (b + 1 < NB) ? (b + 1) : b;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xn[s] = xb[16 * bn + 2 * s];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[0][s], xc[s], h1);
+        int bf = b + RD;
+        bf = (bf >= NB) ? (bf - NB) : bf;
+#pragma unroll
+        for (int d = 0; d + 1 < RD; ++d)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) wr[d][s] = wr[d + 1][s];
+        // rows k >= din of "W1" are the bias / W2 words that follow it in the flat parameter vector:
+        // finite values that meet the zero padding of the x tile, so no clamp and no per-load address math
+        const float* wb = wcol1h + bf * (16 * MLP_H);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          wr[RD - 1][s] = wb[(2 * s) * MLP_H];
+          xc[s] = xn[s];
+        }
+      }
+    }
+    STAMP(12);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       h1[r] = fmaxf(h1[r], 0.0f);
       H1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = h1[r];
     }
+    STAMP(0);
     __syncthreads();  // A
+    // Next tile's gathers are issued only now: vmcnt retires in order, so issuing them before P1 would
+    // put the HBM gather latency in front of every W1 operand wait of P1.
+    if (have_next) {
+      // idx values were gathered one iteration ago (complete by now); only now are they used
+      stage_issue(row_of(itn * 32 + srow, ps_next), xr);  // global -> registers, committed after barrier E
+      rnext = load_row(row_of(itn * 32 + j, pj_next));
+      const long itnn = itn + gridDim.x;
+      if (itnn < ntiles) {  // raw index gather for the tile after next (first used next iteration)
+        uint32_t bb;
+        ps_next = gather_idx(itnn * 32 + srow, bb);
+        pj_next = gather_idx(itnn * 32 + j, bb);
+      }
+    }
+    STAMP(10);
 
     // ---------------------------------------------------------------- P2: layer 2, tile w
     f32x16 h2;
@@ -230,9 +359,24 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
     {
       const float* wl = W2s + h * MLP_LDW + 32 * w + j;  // W2[k + h][32w + j]
       const float* hb = H1T + h * LDT + j;               // h1^T[k + h][row j]
-#pragma unroll 16
-      for (int k = 0; k < MLP_H; k += 2) h2 = MFMA32(wl[k * MLP_LDW], hb[k * LDT], h2);
+      float oa[2][8], ob[2][8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { oa[0][s] = wl[(2 * s) * MLP_LDW]; ob[0][s] = hb[(2 * s) * LDT]; }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            oa[(g + 1) & 1][s] = wl[(16 * (g + 1) + 2 * s) * MLP_LDW];
+            ob[(g + 1) & 1][s] = hb[(16 * (g + 1) + 2 * s) * LDT];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) h2 = MFMA32(oa[g & 1][s], ob[g & 1][s], h2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    STAMP(11);
     {
       float part[NO];
 #pragma unroll
@@ -252,6 +396,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
         if (h == 0) YP[(w * NO + o) * 32 + j] = v;
       }
     }
+    STAMP(1);
     __syncthreads();  // B
 
     // ---------------------------------------------------------------- P3: loss, dlogits, dz2
@@ -263,16 +408,19 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
         y[o] = (((YP[(0 * NO + o) * 32 + j] + YP[(1 * NO + o) * 32 + j]) + YP[(2 * NO + o) * 32 + j]) +
                 YP[(3 * NO + o) * 32 + j]) + lds[MlpLds<NO>::B3 + o];
       if (ACTOR) {
+        uint32_t mbits = 0;
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+          if (rin.mraw[o]) mbits |= (1u << o);
         Categorical<NO> cat;
-        cat.build(y, (tk.mask != nullptr && valid) ? (tk.mask + fr * no) : nullptr, no);
-        const int act = valid ? tk.action[fr] : 0;
+        cat.build_bits(y, mbits, no);
+        const int act = rin.act;
         float lp = 0.0f;
 #pragma unroll
         for (int o = 0; o < NO; ++o)
           if (o == act) lp = cat.logp[o];
-        const float old_lp = valid ? tk.old_logp[fr] : 0.0f;
-        const float gae = valid ? (tk.adv[fr] - adv_mean) * adv_rstd : 0.0f;
-        const float ratio = expf(lp - old_lp);
+        const float gae = (rin.f1 - adv_mean) * adv_rstd;
+        const float ratio = expf(lp - rin.f0);
         const float lo = 1.0f - tk.clip_eps, hi = 1.0f + tk.clip_eps;
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float l1 = ratio * gae, l2 = rc * gae;
@@ -297,8 +445,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
         }
       } else {
         const float v = y[0];
-        const float ov = valid ? tk.old_value[fr] : 0.0f;
-        const float tg = valid ? tk.targets[fr] : 0.0f;
+        const float ov = rin.f0, tg = rin.f1;
         const float diff = v - ov;
         const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
         const float e1 = v - tg, e2 = vclip - tg;
@@ -325,7 +472,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
       dz[r] = (h2[r] > 0.0f) ? acc : 0.0f;
       DZ2T[f * LDT + j] = dz[r];
     }
-    __syncthreads();  // C  (YP is dead from here; DZ1T may be written)
+    STAMP(2);
+    __syncthreads();  // C
 
     // ---------------------------------------------------------------- P4: dh1 tile w, small grads
     f32x16 d1;
@@ -334,39 +482,83 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
     {
       const float* wl = W2s + (32 * w + j) * MLP_LDW + h;  // W2[32w + j][n + h]
       const float* db = DZ2T + h * LDT + j;                // dz2^T[n + h][row j]
-#pragma unroll 16
-      for (int n = 0; n < MLP_H; n += 2) d1 = MFMA32(wl[n], db[n * LDT], d1);
+      float oa[2][8], ob[2][8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { oa[0][s] = wl[2 * s]; ob[0][s] = db[(2 * s) * LDT]; }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            oa[(g + 1) & 1][s] = wl[16 * (g + 1) + 2 * s];
+            ob[(g + 1) & 1][s] = db[(16 * (g + 1) + 2 * s) * LDT];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) d1 = MFMA32(oa[g & 1][s], ob[g & 1][s], d1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     {
       // dW3[f][o] += sum_rows h2[f][row] * dy[o][row];  db3, db2
+      // all loads of an 8-row chunk are issued before their first use (one LDS latency per chunk)
       const float* hrow = H2T + sf * LDT;
-#pragma unroll 8
-      for (int row = 0; row < 32; ++row) {
-        const float hv = hrow[row];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float hv[8], dv[NOH][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = hrow[8 * c + q];
 #pragma unroll
         for (int i = 0; i < NOH; ++i) {
           const int o = 2 * i + og;
-          if (o < NO) aW3[i] = fmaf(hv, DY[o * 32 + row], aW3[i]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dv[i][q] = (o < NO) ? DY[o * 32 + 8 * c + q] : 0.0f;
         }
+#pragma unroll
+        for (int i = 0; i < NOH; ++i)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) aW3[i] = fmaf(hv[q], dv[i][q], aW3[i]);
       }
       if (tid < NO) {
         float s = 0.0f;
-        for (int row = 0; row < 32; ++row) s += DY[tid * 32 + row];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v[16];
+#pragma unroll
+          for (int row = 0; row < 16; ++row) v[row] = DY[tid * 32 + 16 * c + row];
+#pragma unroll
+          for (int row = 0; row < 16; ++row) s += v[row];
+        }
         ab3 += s;
       }
       if (tid < 128) {
-        float s = 0.0f;
         const float* zr = DZ2T + tid * LDT;
-#pragma unroll 8
-        for (int row = 0; row < 32; ++row) s += zr[row];
-        ab21 += s;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v[16];
+#pragma unroll
+          for (int row = 0; row < 16; ++row) v[row] = zr[16 * c + row];
+#pragma unroll
+          for (int row = 0; row < 16; row += 2) { s0 += v[row]; s1 += v[row + 1]; }
+        }
+        ab21 += s0 + s1;
       }
     }
+    STAMP(3);
+    __syncthreads();  // D': every reader of h2^T is done; the tile is reused for dz1^T
+    {
+      // relu'(z1) from the h1^T tile still in LDS (keeps h1 out of the register file across P2-P4)
+      float hm[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      d1[r] = (h1[r] > 0.0f) ? d1[r] : 0.0f;
-      DZ1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = d1[r];
+      for (int r = 0; r < 16; ++r) hm[r] = H1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d1[r] = (hm[r] > 0.0f) ? d1[r] : 0.0f;
+        DZ1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = d1[r];
+      }
     }
+    STAMP(4);
     __syncthreads();  // D
 
     // ---------------------------------------------------------------- P5: weight gradients
@@ -381,42 +573,50 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk) {
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) gW2[t] = MFMA32(ea[(32 * t) * LDT + 2 * s], bz[s], gW2[t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(5);
     {
-      // gW1[k_in tile t][n] += sum_rows x[row][k_in] * dz1^T[n][row];  A straight from HBM/L2
+      // gW1[k_in tile t][n] += sum_rows x[row][k_in] * dz1^T[n][row];  A from the staged x tile
       const float* eb = DZ1T + (32 * w + j) * LDT + h;
+      const float* xa = XS + h * ldx + j;  // x[row 2s + h][32t + j]
       float bz[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) bz[s] = eb[2 * s];
-      const float* xp[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) xp[s] = tk.x + rowx[2 * s + h] * din + j;
-      float ac[16], an[16];
-      auto loadA = [&](int t, float (&ao)[16]) {
-        const bool ok = (32 * t + j) < din;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) ao[s] = ok ? xp[s][32 * t] : 0.0f;
-      };
-      loadA(0, ac);
 #pragma unroll
       for (int t = 0; t < KT1; ++t) {
-        if (t + 1 < KT1) loadA(t + 1, an);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) gW1[t] = MFMA32(ac[s], bz[s], gW1[t]);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) ac[s] = an[s];
+        for (int s = 0; s < 16; ++s) gW1[t] = MFMA32(xa[(2 * s) * ldx + 32 * t], bz[s], gW1[t]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next tile's LDS reads from piling up in VGPRs
       }
       if (tid >= 128) {
-        float s = 0.0f;
         const float* zr = DZ1T + (tid - 128) * LDT;
-#pragma unroll 8
-        for (int row = 0; row < 32; ++row) s += zr[row];
-        ab21 += s;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v[16];
+#pragma unroll
+          for (int row = 0; row < 16; ++row) v[row] = zr[16 * c + row];
+#pragma unroll
+          for (int row = 0; row < 16; row += 2) { s0 += v[row]; s1 += v[row + 1]; }
+        }
+        ab21 += s0 + s1;
       }
     }
-    __syncthreads();  // E: exchange tiles are free for the next row tile
+    STAMP(6);
+    __syncthreads();  // E: every exchange tile and the x tile are free
+    STAMP(7);
+    if (have_next) stage_commit(xr);
+    rin = rnext;
+    __syncthreads();  // F: next x tile visible
+    STAMP(8);
   }
+#ifdef MAVA_STAMPS
+  if (tk.stamps != nullptr && blockIdx.x == 0 && lane == 0) {
+    for (int i = 0; i < 16; ++i) tk.stamps[w * 16 + i] = st_acc[i];
+  }
+#endif
 
   // ------------------------------------------------------------------ epilogue: one slab per block
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
@@ -463,11 +663,14 @@ int pick_xv(const float* x, int din) {
 
 template <int NO, int KT1, bool ACTOR>
 int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
-  static_assert(TrainLds<NO>::END * sizeof(float) <= 163840, "LDS budget exceeded");
-  const size_t lb = (size_t)TrainLds<NO>::END * sizeof(float);
+  const TrainLdsLayout L = make_layout<NO>(KT1);
+  const size_t lb = (size_t)L.end * sizeof(float);
+  MAVA_ARG_CHECK(lb <= 163840, 8,
+                 "ppo_train: %zu bytes of LDS needed (n_out pad %d, input width %d) exceed the 160 KiB of a CU",
+                 lb, NO, tk.din);
   MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR>), dim3(n_slab), dim3(256), lb, s, tk);
+  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR>), dim3(n_slab), dim3(256), lb, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
@@ -475,6 +678,12 @@ int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
 template <int NO, bool ACTOR>
 int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int kt = (tk.din + 31) / 32;
+#ifdef MAVA_FAST_BUILD  // developer iteration: only the BASELINE config-2 instantiations
+  if (kt == 3) return launch_train<NO, 3, ACTOR>(tk, n_slab, s);
+  if (kt == 9) return launch_train<NO, 9, ACTOR>(tk, n_slab, s);
+  mava_set_error("fast build: input width %d not instantiated", tk.din);
+  return MAVA_EARG(9);
+#else
   switch (kt) {
     case 1: return launch_train<NO, 1, ACTOR>(tk, n_slab, s);
     case 2: return launch_train<NO, 2, ACTOR>(tk, n_slab, s);
@@ -486,9 +695,18 @@ int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
       mava_set_error("ppo_train: input width %d > 288 is not instantiated", tk.din);
       return MAVA_EARG(9);
   }
+#endif
 }
 
 }  // namespace
+
+static unsigned long long* g_stamps = nullptr;
+// Diagnostic hook (not part of include/mava_hip.h): device buffer of 40 u64 receiving block 0's per-phase
+// cycle sums when the library is built with -DMAVA_STAMPS; ignored otherwise.
+extern "C" int mava_debug_set_stamps(unsigned long long* p) {
+  g_stamps = p;
+  return MAVA_OK;
+}
 
 extern "C" int mava_adv_stats_blocks(void) { return STATS_BLOCKS; }
 
@@ -511,7 +729,7 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
                                        int n_slab, hipStream_t s) {
   MAVA_ARG_CHECK(din >= 1 && n_actions >= 1 && n_actions <= 32, 0,
                  "mava_ppo_actor_grad_f32: din=%d n_actions=%d unsupported", din, n_actions);
-  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_slab >= 1 && n_slab <= 1024, 1,
+  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_slab >= 1 && n_slab <= 1024 && (long)Rb * A < (1L << 31), 1,
                  "mava_ppo_actor_grad_f32: Rb=%d A=%d n_slab=%d", Rb, A, n_slab);
   MAVA_ARG_CHECK(slab_stride >= mlp_param_count(din, n_actions) + 2, 2,
                  "mava_ppo_actor_grad_f32: slab_stride too small");
@@ -523,6 +741,7 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
   tk.mask = action_mask; tk.action = action; tk.old_logp = old_log_prob; tk.adv = advantages;
   tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
   tk.slab_stride = slab_stride;
+  tk.stamps = g_stamps;
   if (n_actions <= 8) return dispatch_kt<8, true>(tk, n_slab, s);
   if (n_actions <= 16) return dispatch_kt<16, true>(tk, n_slab, s);
   return dispatch_kt<32, true>(tk, n_slab, s);
@@ -534,7 +753,7 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
                                         float clip_eps, float vf_coef, float* slab, long slab_stride,
                                         int n_slab, hipStream_t s) {
   MAVA_ARG_CHECK(din >= 1 && x_share >= 1, 0, "mava_ppo_critic_grad_f32: din=%d x_share=%d", din, x_share);
-  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_slab >= 1 && n_slab <= 1024, 1,
+  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_slab >= 1 && n_slab <= 1024 && (long)Rb * A < (1L << 31), 1,
                  "mava_ppo_critic_grad_f32: Rb=%d A=%d n_slab=%d", Rb, A, n_slab);
   MAVA_ARG_CHECK(slab_stride >= mlp_param_count(din, 1) + 2, 2,
                  "mava_ppo_critic_grad_f32: slab_stride too small");
@@ -545,5 +764,6 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
   tk.xv = pick_xv(critic_input, din); tk.A = A; tk.idx = idx; tk.idx_base = idx_base; tk.Rb = Rb;
   tk.old_value = old_value; tk.targets = targets; tk.clip_eps = clip_eps; tk.vf_coef = vf_coef;
   tk.slab = slab; tk.slab_stride = slab_stride;
+  tk.stamps = g_stamps;
   return dispatch_kt<1, false>(tk, n_slab, s);
 }

@@ -230,6 +230,8 @@ def ppo_actor_grad(params, agents_view, action_mask, action, old_log_prob, advan
             raise ValueError(f"{n}: expected {rows} elements, got {t.numel()}")
     _req(stats, torch.float64, "stats", (lib().mava_adv_stats_blocks(), 2))
     _check_idx(idx, idx_base, Rb, TE)
+    if rows >= 2 ** 31:
+        raise ValueError("trajectory too large: TE*A must be < 2^31 (32-bit row arithmetic in the kernel)")
     _req(slab, torch.float32, "slab")
     if slab.dim() != 2 or slab.shape[1] < P + 2:
         raise ValueError("slab must be (n_slab, >= P+2)")
@@ -258,6 +260,8 @@ def ppo_critic_grad(params, critic_input, x_share: int, old_value, targets, idx,
     if (rows + x_share - 1) // x_share > critic_input.shape[0]:
         raise ValueError("critic_input has too few rows")
     _check_idx(idx, idx_base, Rb, rows // A)
+    if rows >= 2 ** 31:
+        raise ValueError("trajectory too large: TE*A must be < 2^31 (32-bit row arithmetic in the kernel)")
     _req(slab, torch.float32, "slab")
     if slab.dim() != 2 or slab.shape[1] < P + 2:
         raise ValueError("slab must be (n_slab, >= P+2)")

@@ -1,0 +1,48 @@
+"""Diagnostic: per-phase cycle shares of the fused PPO train kernels (needs a library built with
+MAVA_HIPCC_EXTRA="-DMAVA_STAMPS").  Prints, per wave of block 0, the cycles spent in each phase."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mava_amd import ops
+from mava_amd._lib import lib
+
+dev = torch.device("cuda", 0)
+TE, A, O, nA = 128 * 4096, 4, 66, 5
+Rb = TE // 2
+rng = np.random.default_rng(0)
+names = ["P1 layer1", "P2 layer2+head", "P3 loss+dz2", "P4 dh1+sweeps", "P4b dz1 write", "P5a gW2", "P5b gW1", "barrier E",
+         "commit+F", "loop top", "P2a prefetch issue", "P2b mfma loop", "P1a mfma loop", "-", "-", "-"]
+# note: with sub-stamps, "P1 layer1" = epilogue after P1a, "P2 layer2+head" = head part after P2b
+l = lib()
+l.mava_debug_set_stamps.argtypes = [C.c_void_p]
+stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+l.mava_debug_set_stamps(stamps.data_ptr())
+perm = torch.randperm(TE, device=dev).to(torch.int32)
+for which in ("critic", "actor"):
+    if which == "critic":
+        din = A * O
+        params = torch.randn(ops.mlp_param_count(din, 1), device=dev) * 0.05
+        x = torch.randn(TE, din, device=dev)
+        ov, tg = torch.randn(TE * A, device=dev), torch.randn(TE * A, device=dev)
+        slab = torch.zeros(256, params.numel() + 2, device=dev)
+        run = lambda: ops.ppo_critic_grad(params, x, A, ov, tg, perm, 0, Rb, A, 0.2, 0.5, slab)
+    else:
+        din = A + O
+        params = torch.randn(ops.mlp_param_count(din, nA), device=dev) * 0.05
+        x = torch.randn(TE * A, din, device=dev)
+        mask = (torch.rand(TE * A, nA, device=dev) > 0.2).to(torch.uint8); mask[:, 0] = 1
+        act = torch.zeros(TE * A, dtype=torch.int32, device=dev)
+        olp, adv = -torch.rand(TE * A, device=dev) - 1.0, torch.randn(TE * A, device=dev)
+        st = ops.adv_stats(adv, perm, 0, Rb, A)
+        slab = torch.zeros(256, params.numel() + 2, device=dev)
+        run = lambda: ops.ppo_actor_grad(params, x, mask, act, olp, adv, st, perm, 0, Rb, A, nA, 0.2, 0.01, slab)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); run(); b.record(); torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(4, 16)
+    tot = s.sum(1)
+    print(f"== {which}: launch {a.elapsed_time(b):.3f} ms, block 0 cycles per wave {tot.tolist()}, 128 tiles")
+    for i, n in enumerate(names):
+        print(f"   {n:16s} " + "  ".join(f"{s[w, i] / 128:8.0f}" for w in range(4)) + f"   ({100 * s[0, i] / tot[0]:5.1f} %)")

@@ -65,21 +65,24 @@ __device__ inline void stf(float* p, const float (&o)[VEC]) {
   *reinterpret_cast<typename VecT<VEC>::f*>(p) = v;
 }
 
-// One block = NC waves = one strip of 64*VEC columns.  Slabs of L*NC time steps are walked from
-// the end of the rollout to the start; T <= L*NC (the BASELINE shapes) is a single slab.
-template <int VEC, int L, int NC>
-__global__ __launch_bounds__(64 * NC) void gae_kernel(
+// One block = one strip of CB = LPC*VEC columns; the NC time chunks of a slab are spread over
+// NC groups of LPC lanes (LPC = 64: one wave per chunk; LPC = 16 with VEC = 4: a wave covers four chunks
+// and still reads 256 contiguous bytes per chunk row).  Slabs of L*NC time steps are walked from the end
+// of the rollout to the start; T <= L*NC (the BASELINE shapes) is a single slab.
+template <int VEC, int L, int NC, int LPC>
+__global__ __launch_bounds__(LPC * NC) void gae_kernel(
     const float* __restrict__ reward, const float* __restrict__ value,
     const uint8_t* __restrict__ done, const float* __restrict__ last_val,
     const uint8_t* __restrict__ last_done, int T, int N, float gamma, float lambda,
     float* __restrict__ adv, float* __restrict__ tgt) {
-  __shared__ float sP[NC][64 * VEC];
-  __shared__ float sS[NC][64 * VEC];
-  __shared__ float sAin[64 * VEC];  // advantage entering the current slab from later time
+  constexpr int CB = LPC * VEC;
+  __shared__ float sP[NC][CB];
+  __shared__ float sS[NC][CB];
+  __shared__ float sAin[CB];  // advantage entering the current slab from later time
 
-  const int lane = threadIdx.x & 63;
-  const int chunk = threadIdx.x >> 6;
-  const long col = ((long)blockIdx.x * 64 + lane) * VEC;
+  const int chunk = threadIdx.x / LPC;
+  const int lc = threadIdx.x - chunk * LPC;
+  const long col = ((long)blockIdx.x * LPC + lc) * VEC;
   const bool live = col < N;
   const bool shifted = last_done != nullptr;  // recurrent masking
   const float gl = gamma * lambda;
@@ -89,11 +92,11 @@ __global__ __launch_bounds__(64 * NC) void gae_kernel(
 
   if (chunk == 0) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) sAin[lane * VEC + i] = 0.0f;
+    for (int i = 0; i < VEC; ++i) sAin[lc * VEC + i] = 0.0f;
   }
 
   for (int slab = n_slab - 1; slab >= 0; --slab) {
-    const int t0 = slab * slab_len + chunk * L;  // first step of this wave's chunk
+    const int t0 = slab * slab_len + chunk * L;  // first step of this thread's chunk
     float r[L][VEC], v[L + 1][VEC], nd[L][VEC];
 
     // ---- issue every load of the chunk before any arithmetic
@@ -128,7 +131,6 @@ __global__ __launch_bounds__(64 * NC) void gae_kernel(
     }
     // Steps past T inside the chunk (ragged T) must behave as identity: with r=v=0, nd=0 they
     // produce S=0 and P=0, but the bootstrap value must then sit at the last *valid* step.
-    // Move last_val to v[s+1] of the last valid step.
     if (live && t0 < T && t0 + L > T) {
       float lv[VEC];
       ldf<VEC>(last_val + col, lv);
@@ -163,18 +165,18 @@ __global__ __launch_bounds__(64 * NC) void gae_kernel(
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      sP[chunk][lane * VEC + i] = p[i];
-      sS[chunk][lane * VEC + i] = a[i];
+      sP[chunk][lc * VEC + i] = p[i];
+      sS[chunk][lc * VEC + i] = a[i];
     }
     __syncthreads();
 
     // ---- compose the later chunks of this slab (and the carry from later slabs)
     float ain[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) ain[i] = sAin[lane * VEC + i];
+    for (int i = 0; i < VEC; ++i) ain[i] = sAin[lc * VEC + i];
     for (int k = NC - 1; k > chunk; --k) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) ain[i] = sS[k][lane * VEC + i] + sP[k][lane * VEC + i] * ain[i];
+      for (int i = 0; i < VEC; ++i) ain[i] = sS[k][lc * VEC + i] + sP[k][lc * VEC + i] * ain[i];
     }
 
     // ---- fix up and store
@@ -197,20 +199,20 @@ __global__ __launch_bounds__(64 * NC) void gae_kernel(
       __syncthreads();  // everyone has read sAin / sP / sS of this slab
       if (chunk == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) sAin[lane * VEC + i] = a[i] + p[i] * ain[i];
+        for (int i = 0; i < VEC; ++i) sAin[lc * VEC + i] = a[i] + p[i] * ain[i];
       }
       __syncthreads();
     }
   }
 }
 
-template <int VEC, int L, int NC>
+template <int VEC, int L, int NC, int LPC>
 int launch_gae(const float* reward, const float* value, const uint8_t* done, const float* last_val,
                const uint8_t* last_done, int T, int N, float gamma, float lambda, float* adv,
                float* tgt, hipStream_t s) {
-  const int cols_per_block = 64 * VEC;
-  dim3 grid(mava_cdiv(N, cols_per_block)), block(64 * NC);
-  hipLaunchKernelGGL((gae_kernel<VEC, L, NC>), grid, block, 0, s, reward, value, done, last_val,
+  const int cols_per_block = LPC * VEC;
+  dim3 grid(mava_cdiv(N, cols_per_block)), block(LPC * NC);
+  hipLaunchKernelGGL((gae_kernel<VEC, L, NC, LPC>), grid, block, 0, s, reward, value, done, last_val,
                      last_done, T, N, gamma, lambda, adv, tgt);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
@@ -233,31 +235,33 @@ extern "C" int mava_gae_f32(const float* reward, const float* value, const uint8
   if (T == 0 || N == 0) return MAVA_OK;
   MAVA_ARG_CHECK(reward && value && done && last_val && adv && tgt, 1,
                  "mava_gae_f32: null pointer argument");
-  // vector width: columns must stay VEC-aligned in every time row
-  int vec = 1;
-  if (N % 4 == 0) vec = 4;
-  else if (N % 2 == 0) vec = 2;
-  // Small problems: prefer more, narrower strips so the grid still covers the chip.
-  if (vec == 4 && N < 256 * 64 * 4) vec = (N >= 256 * 64 * 2) ? 2 : 1;
+#define GAE_ARGS reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s
+  // columns must stay VEC-aligned in every time row
+  const int align = (N % 4 == 0) ? 4 : ((N % 2 == 0) ? 2 : 1);
   int variant = g_gae_variant;
-  if (variant == 1) vec = 1;
-  if (variant == 2 && N % 2 == 0) vec = 2;
-  if (variant == 3 && N % 4 == 0) vec = 4;
-  const bool deep = (variant >= 10);  // 16 chunks of 8 steps instead of 8 chunks of 16
-  if (deep) {
-    int vv = variant - 10;
-    if (vv == 1) vec = 1;
-    if (vv == 2 && N % 2 == 0) vec = 2;
-    if (vv == 4 && N % 4 == 0) vec = 4;
-    switch (vec) {
-      case 1: return launch_gae<1, 8, 16>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
-      case 2: return launch_gae<2, 8, 16>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
-      default: return launch_gae<4, 8, 16>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
-    }
+  if (variant == 0) {
+    // default (tools/gae_sweep.py on MI355X): 16-byte accesses in 128-column strips once there are
+    // >= 128 strips, 32-column strips below that, scalar columns for odd N
+    if (align == 4 && N >= 128 * 128) variant = 43;
+    else if (align == 4 && N >= 32 * 64) variant = 45;
+    else if (align >= 2 && N >= 32 * 64) variant = 24;
+    else variant = 1;
   }
-  switch (vec) {
-    case 1: return launch_gae<1, 16, 8>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
-    case 2: return launch_gae<2, 16, 8>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
-    default: return launch_gae<4, 16, 8>(reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s);
+  switch (variant) {
+    case 41: if (align == 4) return launch_gae<4, 4, 32, 16>(GAE_ARGS); break;   // CB 64, 512 threads
+    case 42: if (align == 4) return launch_gae<4, 8, 16, 16>(GAE_ARGS); break;   // CB 64, 256 threads
+    case 43: if (align == 4) return launch_gae<4, 4, 32, 32>(GAE_ARGS); break;   // CB 128, 1024 threads
+    case 44: if (align == 4) return launch_gae<4, 16, 8, 16>(GAE_ARGS); break;   // CB 64, 128 threads
+    case 45: if (align == 4) return launch_gae<4, 4, 32, 8>(GAE_ARGS); break;    // CB 32, 256 threads
+    case 46: if (align == 4) return launch_gae<4, 8, 16, 8>(GAE_ARGS); break;    // CB 32, 128 threads
+    case 47: if (align == 4) return launch_gae<4, 2, 64, 16>(GAE_ARGS); break;   // CB 64, 1024 threads
+    case 24: if (align >= 2) return launch_gae<2, 4, 32, 16>(GAE_ARGS); break;   // CB 32, 512 threads
+    case 21: if (align >= 2) return launch_gae<2, 8, 16, 32>(GAE_ARGS); break;   // CB 64, 512 threads
+    case 22: if (align >= 2) return launch_gae<2, 4, 32, 32>(GAE_ARGS); break;   // CB 64, 1024 threads
+    case 23: if (align >= 2) return launch_gae<2, 16, 8, 64>(GAE_ARGS); break;   // CB 128, 512 threads
+    case 11: return launch_gae<1, 8, 16, 64>(GAE_ARGS);                            // CB 64, 1024 threads
+    default: break;
   }
+  return launch_gae<1, 16, 8, 64>(GAE_ARGS);  // CB 64, 512 threads (any N)
+#undef GAE_ARGS
 }

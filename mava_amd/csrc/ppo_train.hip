@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   };
   auto stage_commit = [&](const float (&xr)[NR]) { stage_write<NR>(XS + srow * ldx + l8, din, l8, xr); };
 
-  constexpr int RD = (2 * KT1 < 4) ? 2 * KT1 : 4;  // W1 operand ring depth (batches of 8 k-steps)
+  // W1 operand ring depth (batches of 8 k-steps); must divide the batch count 2*KT1
+  constexpr int RD = ((2 * KT1) % 3 == 0) ? 3 : (((2 * KT1) % 4 == 0) ? 4 : 2);
   float wr[RD][8];
   const float* const wcol1h = wcol1 + h * MLP_H;  // W1[k + h][32w + j] = wcol1h[k * 128]
 #pragma unroll
@@ -303,31 +304,39 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       // batches 0..RD-1 for the next row tile.  x operands come from the staged LDS tile one batch ahead.
       const float* xb = XS + j * ldx + h;  // x[row j][k + h]
       constexpr int NB = 2 * KT1;          // batches of 8 k-steps (16 inputs)
-      float xc[8], xn[8];
+      static_assert(NB % RD == 0, "ring depth must divide the batch count");
+      // Ring slot d holds batch g*RD + d (W1 operands from L2) and xo[d] its x operands (LDS).  Slots are
+      // static inside a group of RD batches - no register copies next to the MFMAs - and groups form a
+      // runtime loop.  A consumed slot is refilled with batch b+RD, wrapping to the head batches of the NEXT
+      // row tile, so the ring is already primed when the next tile starts.
+      // Rows k >= din of "W1" are the bias / W2 words that follow it in the flat parameter vector: finite
+      // values that meet the zero padding of the x tile, so no clamp and no per-load address math.
+      float xo[RD][8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) xc[s] = xb[2 * s];
+      for (int s = 0; s < 8; ++s) xo[0][s] = xb[2 * s];
 #pragma unroll 1
-      for (int b = 0; b < NB; ++b) {
-        const int bn = (b + 1 < NB) ? (b + 1) : b;
+      for (int g = 0; g < NB / RD; ++g) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) xn[s] = xb[16 * bn + 2 * s];
+        for (int d = 0; d < RD; ++d) {
+          const int b = g * RD + d;
+          const int bn = (b + 1 < NB) ? (b + 1) : b;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[0][s], xc[s], h1);
-        int bf = b + RD;
-        bf = (bf >= NB) ? (bf - NB) : bf;
+          for (int s = 0; s < 8; ++s) xo[(d + 1) % RD][s] = xb[16 * bn + 2 * s];
 #pragma unroll
-        for (int d = 0; d + 1 < RD; ++d)
+          for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[d][s], xo[d][s], h1);
+          // refill the slot consumed ONE batch ago (its MFMAs have retired: no write-after-read wait on
+          // operands still being read) with batch b-1+RD
+          int bf = b - 1 + RD;
+          bf = (bf >= NB) ? (bf - NB) : bf;
+          const float* wb = wcol1h + bf * (16 * MLP_H);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) wr[d][s] = wr[d + 1][s];
-        // rows k >= din of "W1" are the bias / W2 words that follow it in the flat parameter vector:
-        // finite values that meet the zero padding of the x tile, so no clamp and no per-load address math
-        const float* wb = wcol1h + bf * (16 * MLP_H);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          wr[RD - 1][s] = wb[(2 * s) * MLP_H];
-          xc[s] = xn[s];
+          for (int s = 0; s < 8; ++s) wr[(d + RD - 1) % RD][s] = wb[(2 * s) * MLP_H];
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // trailing refill of the last slot (batch NB-1+RD wraps to head batch RD-1 of the next tile)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wr[RD - 1][s] = wcol1h[(16 * (RD - 1) + 2 * s) * MLP_H];
     }
     STAMP(12);
 #pragma unroll

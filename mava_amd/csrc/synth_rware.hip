@@ -48,54 +48,70 @@ struct SynthArgs {
   int is_reset;
 };
 
-// one thread per (env, agent)
+__device__ __forceinline__ float synth_raw_feature(uint32_t ent, int f, const SynthArgs& a) {
+  // raw view feature f of entity ent = env_id*A + agent (identical formula in oracle/synth_env.py)
+  if (f < 2) {
+    Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
+    return (float)((f == 0 ? cm.x : cm.y) % 10u);
+  }
+  const int c = (f - 2) >> 4, q = (f - 2) & 15;
+  Philox4 r = philox4x32_10(ent, a.t, (uint32_t)c, ENV_STREAM, a.seed_lo, a.seed_hi);
+  const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+  return (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
+}
+
+// Flat, fully coalesced generation: one thread per OUTPUT float of agents_view and global_state (every
+// value is a pure function of (entity, step, feature) on the counter-based RNG, so no thread ever needs
+// another thread's draw), followed by one thread per (env, agent) for the small per-agent / per-env data.
 __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int E = a.E, A = a.A, O = a.O;
-  if (gid >= E * A) return;
-  const int e = gid / A, ag = gid - e * A;
-  const uint32_t env_id = a.env_offset + (uint32_t)e;
+  const uint32_t E = a.E, A = a.A, O = a.O, W = A + O;
+  const uint32_t n_av = E * A * W;
+  const uint32_t n_gs = E * (uint32_t)a.gs_tiles * A * O;
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid < n_av) {
+    const uint32_t row = gid / W, col = gid - row * W;
+    const uint32_t e = row / A, ag = row - e * A;
+    float v;
+    if (col < A) {
+      v = (col == ag) ? 1.0f : 0.0f;
+    } else {
+      v = synth_raw_feature((a.env_offset + e) * A + ag, (int)(col - A), a);
+    }
+    a.agents_view[gid] = v;
+    return;
+  }
+  if (gid < n_av + n_gs) {
+    const uint32_t i = gid - n_av;
+    const uint32_t AO = A * O;
+    const uint32_t et = i / AO, c = i - et * AO;   // (env, tile), column in the concatenated state
+    const uint32_t e = et / (uint32_t)a.gs_tiles;
+    const uint32_t ag = c / O, f = c - ag * O;
+    a.global_state[i] = synth_raw_feature((a.env_offset + e) * A + ag, (int)f, a);
+    return;
+  }
+  const uint32_t k = gid - n_av - n_gs;
+  if (k >= E * A) return;
+  const uint32_t e = k / A, ag = k - e * A;
+  const uint32_t env_id = a.env_offset + e;
 
   // ---- per-env draws (recomputed by every agent thread of the env: identical values)
   Philox4 ev = philox4x32_10(env_id, a.t, 0u, ENV_STREAM ^ 1u, a.seed_lo, a.seed_hi);
-  const int sc_old = a.is_reset ? 0 : a.step_count[gid];
+  const int sc_old = a.is_reset ? 0 : a.step_count[k];
   const float rew = (!a.is_reset && u01_open(ev.x) < 0.02f) ? 1.0f : 0.0f;
   const int sc_new = sc_old + 1;
   const bool term = !a.is_reset && ((sc_new >= a.time_limit) || (u01_open(ev.y) < 0.002f));
   const int sc_obs = (a.is_reset || term) ? 0 : sc_new;
 
-  // ---- this agent's raw view
-  float* av = a.agents_view + ((long)e * A + ag) * (A + O);
-  for (int i = 0; i < A; ++i) av[i] = (i == ag) ? 1.0f : 0.0f;
-  const uint32_t ent = env_id * (uint32_t)A + (uint32_t)ag;
-  Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
-  float* raw = av + A;
-  if (O > 0) raw[0] = (float)(cm.x % 10u);
-  if (O > 1) raw[1] = (float)(cm.y % 10u);
-  const int nchunk = (O - 2 + 15) / 16;
-  for (int c = 0; c < nchunk; ++c) {
-    Philox4 r = philox4x32_10(ent, a.t, (uint32_t)c, ENV_STREAM, a.seed_lo, a.seed_hi);
-    const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int f = 2 + 16 * c + q;
-      if (f < O) raw[f] = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
-    }
-  }
-  // global state: raw view of agent ag at column block ag, in every tile
-  for (int tl = 0; tl < a.gs_tiles; ++tl) {
-    float* gs = a.global_state + ((long)e * a.gs_tiles + tl) * ((long)A * O) + (long)ag * O;
-    for (int f = 0; f < O; ++f) gs[f] = raw[f];
-  }
-  uint8_t* mk = a.action_mask + ((long)e * A + ag) * a.nA;
+  Philox4 cm = philox4x32_10(env_id * A + ag, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
+  uint8_t* mk = a.action_mask + (long)k * a.nA;
   for (int i = 0; i < a.nA; ++i) mk[i] = 1;
   if (a.nA > 1 && ((cm.z & 0xFFu) < 51u)) mk[1] = 0;
-  a.obs_step_count[(long)e * A + ag] = sc_obs;
-  a.step_count[gid] = sc_obs;
+  a.obs_step_count[k] = sc_obs;
+  a.step_count[k] = sc_obs;
 
   if (!a.is_reset) {
-    a.reward[(long)e * A + ag] = rew;
-    a.done[(long)e * A + ag] = term ? 1 : 0;
+    a.reward[k] = rew;
+    a.done[k] = term ? 1 : 0;
   }
   // ---- per-env state and episode metrics (agent 0's thread)
   if (ag == 0) {
@@ -148,7 +164,9 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
   a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;
   a.reward = reward; a.done = done; a.info_return = info_return; a.info_length = info_length;
   a.info_terminal = info_terminal; a.is_reset = is_reset;
-  hipLaunchKernelGGL(synth_rware_kernel, dim3(mava_cdiv((long)E * A, 256)), dim3(256), 0, s, a);
+  const long total = (long)E * A * (A + O) + (long)E * gs_tiles * A * O + (long)E * A;
+  MAVA_ARG_CHECK(total < (1L << 32), 4, "mava_synth_rware_step: %ld output elements exceed 32-bit indexing", total);
+  hipLaunchKernelGGL(synth_rware_kernel, dim3(mava_cdiv(total, 256)), dim3(256), 0, s, a);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

@@ -315,3 +315,28 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab):
     assert_close(g, g2, 1e-9, "oracle vs torch autograd")
     assert_close(got[:P], g, 1e-4, "critic grad")
     assert_close(got[P:P + 1], np.array([vl]), 1e-5, "value loss", scale=1.0)
+
+
+@pytest.mark.parametrize("variant", [1, 11, 21, 22, 23, 24, 41, 42, 43, 44, 45, 46, 47])
+@pytest.mark.parametrize("T,N,rec", [(128, 16384, False), (37, 136, True), (300, 264, False)])
+def test_gae_variants(dev, variant, T, N, rec):
+    """Every chunk/lane mapping of the GAE kernel gives the same scan (incl. ragged T and multi-slab T)."""
+    from mava_amd import ops
+    from mava_amd._lib import lib
+
+    rng = np.random.default_rng(variant * 7 + T)
+    r = rng.standard_normal((T, N)).astype(np.float32)
+    v = rng.standard_normal((T, N)).astype(np.float32)
+    d = rng.random((T, N)) < 0.03
+    lv = rng.standard_normal(N).astype(np.float32)
+    ld = (rng.random(N) < 0.1) if rec else None
+    want, want_t = po.gae(r, v, d, lv, 0.99, 0.95, last_done=ld)
+    lib().mava_gae_set_variant(variant)
+    try:
+        adv, tgt = ops.gae(_t(r, dev), _t(v, dev), _t(d, dev), _t(lv, dev), 0.99, 0.95,
+                           last_done=None if ld is None else _t(ld, dev))
+        torch.cuda.synchronize()
+    finally:
+        lib().mava_gae_set_variant(0)
+    assert_close(adv.cpu().numpy(), want, 1e-5, f"adv variant {variant}")
+    assert_close(tgt.cpu().numpy(), want_t, 1e-5, f"tgt variant {variant}")

@@ -36,6 +36,7 @@ int mava_gae_f32(const float* reward, const float* value, const uint8_t* done,
                  const float* last_val, const uint8_t* last_done, int T, int N, float gamma,
                  float lambda, float* adv, float* tgt, mava_stream_t s);
 int mava_gae_set_variant(int variant); /* bench-only tuning knob, 0 = default */
+int mava_policy_set_variant(int variant); /* 0 = per-wave acting kernel (default), 2 = block-cooperative kernels */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam(eps=1e-5)) per network,
  *      mava/systems/ppo/ff_mappo.py:359-366 (definition) and :241-250 (application);

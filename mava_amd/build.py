@@ -20,6 +20,7 @@ HIP_SOURCES = [
     "gae.hip",
     "adam.hip",
     "mlp_policy.hip",
+    "mlp_coop.hip",
     "ppo_train.hip",
     "synth_rware.hip",
     "engine.hip",

@@ -340,3 +340,41 @@ def test_gae_variants(dev, variant, T, N, rec):
         lib().mava_gae_set_variant(0)
     assert_close(adv.cpu().numpy(), want, 1e-5, f"adv variant {variant}")
     assert_close(tgt.cpu().numpy(), want_t, 1e-5, f"tgt variant {variant}")
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_policy_kernels_both_variants(dev, variant):
+    """The per-wave register-resident kernel (default) and the block-cooperative acting kernels agree with
+    the oracle on logits, values, log-probs and sampled actions."""
+    from mava_amd import ops
+    from mava_amd._lib import lib
+
+    rng = np.random.default_rng(77)
+    E, A, O, nA = 257, 4, 66, 5  # ragged last tile
+    rows = E * A
+    fa = _net(rng, O + A, nA, 1.0).astype(np.float32)
+    fc = _net(rng, A * O, 1, 1.0).astype(np.float32)
+    av = rng.standard_normal((rows, O + A)).astype(np.float32)
+    gs = rng.standard_normal((E, A * O)).astype(np.float32)
+    mask = rng.random((rows, nA)) > 0.2
+    mask[:, 0] = True
+    lib().mava_policy_set_variant(variant)
+    try:
+        action, logp, value, logits = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                                      n_actions=nA, critic_share=A, seed=99, step=5, row_offset=7,
+                                                      want_logits=True)
+        raw = ops.mlp_forward(_t(fc, dev), A * O, 1, _t(gs, dev), rows=rows, x_share=A)
+        torch.cuda.synchronize()
+    finally:
+        lib().mava_policy_set_variant(0)
+    y = po.mlp_forward(po.mlp_unflatten(fa.astype(np.float64), O + A, nA), av.astype(np.float64))
+    v = po.mlp_forward(po.mlp_unflatten(fc.astype(np.float64), A * O, 1), gs.astype(np.float64))[:, 0]
+    assert_close(logits.cpu().numpy(), y, 1e-5, "logits")
+    assert_close(value.cpu().numpy(), np.repeat(v, A), 1e-5, "value")
+    assert_close(raw.cpu().numpy()[:, 0], np.repeat(v, A), 1e-5, "raw forward")
+    z = po.masked_logits(y, mask)
+    u = philox.policy_uniforms(99, 5, rows, nA, row_offset=7)
+    a_or = po.gumbel_argmax(z, u)
+    a = action.cpu().numpy()
+    assert (a != a_or).mean() < 0.005
+    assert_close(logp.cpu().numpy(), po.log_softmax(z)[np.arange(rows), a], 1e-5, "log_prob")

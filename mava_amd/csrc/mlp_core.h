@@ -112,7 +112,9 @@ __device__ __forceinline__ void mlp_l1_forward(const float* __restrict__ xrow, i
   const int nfull = din / STEP;
   const float* wbase = W1g + j;
 
-  float xc[XV], wc[XV][4];
+  // Two static operand buffers in ping-pong (no register copies next to the MFMAs, every load
+  // unconditional so the compiler can keep counted vmcnt waits): chunk c+1 streams in while chunk c computes.
+  float xa[XV], wa[XV][4], xb2[XV], wb2[XV][4];
   auto load = [&](int c, float (&xo)[XV], float (&wo)[XV][4]) {
     const int k0 = c * STEP + XV * h;
     typename XVec<XV>::T xv = *reinterpret_cast<const typename XVec<XV>::T*>(xrow + k0);
@@ -124,29 +126,22 @@ __device__ __forceinline__ void mlp_l1_forward(const float* __restrict__ xrow, i
       for (int t = 0; t < 4; ++t) wo[m][t] = wbase[(k0 + m) * MLP_H + 32 * t];
     }
   };
-  if (nfull > 0) load(0, xc, wc);
-  for (int c = 0; c < nfull; ++c) {
-    float xn[XV], wn[XV][4];
-    if (c + 1 < nfull) {
-      load(c + 1, xn, wn);
-    } else {
-#pragma unroll
-      for (int m = 0; m < XV; ++m) {
-        xn[m] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wn[m][t] = 0.f;
-      }
-    }
+  auto compute = [&](const float (&xo)[XV], const float (&wo)[XV][4]) {
 #pragma unroll
     for (int m = 0; m < XV; ++m)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) z[t] = MFMA32(wc[m][t], xc[m], z[t]);
-#pragma unroll
-    for (int m = 0; m < XV; ++m) {
-      xc[m] = xn[m];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wc[m][t] = wn[m][t];
+      for (int t = 0; t < 4; ++t) z[t] = MFMA32(wo[m][t], xo[m], z[t]);
+  };
+  if (nfull > 0) {
+    load(0, xa, wa);
+    int c = 0;
+    for (; c + 1 < nfull; c += 2) {
+      load(c + 1, xb2, wb2);
+      compute(xa, wa);
+      load((c + 2 < nfull) ? (c + 2) : (nfull - 1), xa, wa);  // clamped: the last one is a harmless reload
+      compute(xb2, wb2);
     }
+    if (c < nfull) compute(xa, wa);
   }
   // tail: remaining inputs in natural pairs (k, k+1), guarded
   for (int k0 = nfull * STEP; k0 < din; k0 += 2) {

@@ -158,6 +158,17 @@ def main() -> None:
                    "parallelism": f"dp{world}"},
     }
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json): counters
+    # cannot be read from inside this process, so the measured figures of the same workload are attached.
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pass
+    default_shape = (args.envs == 4096 and args.update_batch_size == 1 and args.scenario == "tiny-4ag"
+                     and args.system == "ff_mappo")
+
     if rank == 0 and L.timers:
         timers = {k: _ev_ms(v) for k, v in L.timers.items()}
         avg = {k: sum(v) / len(v) for k, v in timers.items() if v}
@@ -171,13 +182,16 @@ def main() -> None:
         tf_a = flop_a / (avg["actor_grad"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "ppo_train_kernel<critic> (fused fwd+loss+bwd+dW)", "bound": "mfma",
                            "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf_c / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
+                           "traffic": (traffic.get("ppo_train_kernel<1, 9, false>", {}).get("hbm_bytes_uncorrected")
+                                       if default_shape else None),
                            "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c}
         gae_bytes = 17 * T * E * A + 4 * E * A
         gbs = gae_bytes / (avg["gae"] * 1e-3) / 1e9
         out["roofline_gae"] = {"kernel": "gae_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_peak": gbs / 6290.0,
-                               "traffic": None, "avg_launch_us": avg["gae"] * 1e3, "bytes_per_launch": gae_bytes}
+                               "traffic": (traffic.get("gae_kernel", {}).get("hbm_bytes_corrected") if default_shape else None),
+                               "avg_launch_us": avg["gae"] * 1e3, "bytes_per_launch": gae_bytes}
         out["roofline_actor"] = {"kernel": "ppo_train_kernel<actor>", "bound": "mfma", "achieved": tf_a,
                                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_a / F32_MFMA_PEAK_TFLOPS,
                                  "avg_launch_ms": avg["actor_grad"], "flop_per_launch": flop_a}

@@ -135,6 +135,56 @@ int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int 
                           float* reward, uint8_t* done, float* info_return, int32_t* info_length,
                           uint8_t* info_terminal, mava_stream_t s);
 
+/* ---- recurrent systems (rec_ippo / rec_mappo): mava/networks.py:238-331 (ScannedRNN GRU with
+ *      reset-on-done, RecurrentActor, RecurrentValueNet), mava/systems/ppo/rec_mappo.py:91-149,
+ *      :210-266, :334-365.  Internal activations use the "T32" tile layout: element (row, f) of a
+ *      (rows x N) matrix lives at ((row/32)*N + f)*32 + row%32; rows is a multiple of 32.  A sequence batch
+ *      is time-major: row = t*Rm + m, m = (local env)*A + agent; external trajectory arrays are (T,E,A,..)
+ *      and env ids come from idx (Rm/A entries, a slice of the env permutation) or the identity. */
+
+/* Y = act(X W + b) [masked by gate > 0]; X is T32 (rows x K) or, with x_rowmajor, the external row-major
+ * source gathered per batch row; W (K x N) row-major with row stride ldw; Y T32 (rows x N). */
+int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+                       int x_share, const float* w, int ldw, const float* bias, const float* gate,
+                       float* y, int K, int N, int rows, int relu, mava_stream_t s);
+
+/* per-block slabs of dW = X^T Y (K x N row-major) followed by db = colsum(Y) when want_bias. */
+int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+                     int x_share, const float* y, int K, int N, int rows, int want_bias, float* slab,
+                     long slab_stride, int n_slab, mava_stream_t s);
+
+/* GRU over T steps (flax GRUCell; hidden state zeroed where done enters the step).  gi = W_i x + b_i
+ * precomputed (T32, T*Rm x 384); wh (128 x 384) = [hr|hz|hn]; outputs hs (T32, h after each step) and,
+ * for training, hprev (masked h entering each step) and saved (T*Rm x 512 = [r|z|n|W_hn h + b_hn]). */
+int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+                          const float* h0, int h0_t32, const float* wh, const float* bhn,
+                          const float* gi, float* hs, float* hprev, float* saved, mava_stream_t s);
+
+/* BPTT through the same scan: dh_out (T32) is the gradient reaching each h_t from the output path;
+ * writes dgi and dgh (T32, T*Rm x 384: gradients w.r.t. the input-side and hidden-side gate pre-activations). */
+int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+                          const float* wh, const float* saved, const float* hprev, const float* dh_out,
+                          float* dgi, float* dgh, mava_stream_t s);
+
+/* sequence losses on T32 logits / values: rec_mappo.py:210-242 and :244-266 (after the re-unroll);
+ * loss_partials: (n_blocks, 2) partial sums already divided by the element count. */
+int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const int32_t* idx,
+                            const float* logits, const uint8_t* mask, const int32_t* action,
+                            const float* old_log_prob, const float* advantages, const double* adv_stats,
+                            int n_stats, float clip_eps, float ent_coef, float* dlogits,
+                            float* loss_partials, int n_blocks, mava_stream_t s);
+int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, const int32_t* idx, const float* values,
+                             const float* old_value, const float* targets, float clip_eps, float vf_coef,
+                             float* dvalues, float* loss_partials, int n_blocks, mava_stream_t s);
+
+/* rollout epilogue: masked Categorical sample + log_prob from T32 logits of one step (rows = E*A). */
+int mava_seq_sample_f32(int rows, int n_actions, const float* logits, const uint8_t* mask, uint64_t seed,
+                        uint32_t step, uint32_t row_offset, int greedy, int32_t* action, float* log_prob,
+                        mava_stream_t s);
+
+/* T32 <-> row-major conversion of a (rows x N) matrix. */
+int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,14 @@ _SIGNATURES = {
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
     "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, u64, u32, u32, i32] + [vp] * 15,
+    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
+    "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "mava_gru_scan_bwd_f32": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, i32, vp],
+    "mava_seq_critic_loss_f32": [i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp],
+    "mava_seq_sample_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
+    "mava_t32_convert_f32": [vp, i32, i32, i32, vp, vp],
 }
 _RESTYPES = {"mava_last_error": C.c_char_p}
 

@@ -23,6 +23,8 @@ HIP_SOURCES = [
     "mlp_coop.hip",
     "ppo_train.hip",
     "synth_rware.hip",
+    "rec_dense.hip",
+    "rec_gru.hip",
     "engine.hip",
 ]
 CPP_SOURCES = ["api.cpp"]

@@ -1,0 +1,332 @@
+// Building blocks of the recurrent PPO path (rec_ippo / rec_mappo; mava/networks.py:238-331):
+// dense layers with register-resident weights and the X^T Y weight-gradient product.
+//
+// Internal activation layout "T32": a (rows x N) matrix is stored as 32-row tiles, feature-major
+// inside a tile:  elem(row, f) at ((row / 32) * N + f) * 32 + (row % 32).  In this layout an MFMA
+// accumulator of the transposed product (feature in the register, batch row on the lane) is read and
+// written with fully coalesced 128-byte accesses and can be used as the B operand of the next layer
+// straight from memory; the X^T Y product stages tiles in LDS as [feature][33] and walks features on
+// the lanes (conflict-free).  External tensors (observations, masks, ...) stay row-major and are
+// gathered on load.  rows must be a multiple of 32 (checked on the host).
+//
+// mava_rec_dense_f32:  Y = act(X W + b) [* (G > 0)]   - every wave keeps its slice of W (<= 192
+//   registers) for the whole launch; persistent blocks walk row tiles, no LDS, no barriers when the
+//   input is T32.
+// mava_rec_xty_f32:    dW = X^T Y, db = colsum(Y) as per-block slabs (fixed-order reduction elsewhere).
+#include "mlp_core.h"
+
+namespace {
+
+struct DenseTask {
+  const float* x;        // T32 (rows x K) or row-major gather source
+  int x_rowmajor;        // 1: x is row-major (rows_x x K); row r of the batch reads x[xrow(r)]
+  // row-major gather (time-major trajectory): batch row q -> t = q / Rm, m = q % Rm, env = idx[m / A],
+  // agent = m % A, source row = ((t * E + env) * A + agent) / xshare
+  const int32_t* idx;    // (Rm / A) env ids of the minibatch, or null (identity)
+  int Rm, E, A, xshare;
+  const float* w;        // (K x N) row-major, row stride ldw
+  int ldw;
+  const float* bias;     // (N) or null
+  const float* gate;     // T32 (rows x N) or null: output multiplied by (gate > 0)
+  float* y;              // T32 (rows x N)
+  int K, N, rows, relu;
+};
+
+__device__ __forceinline__ long gather_row(const DenseTask& tk, int q) {
+  const int t = q / tk.Rm, m = q - t * tk.Rm;
+  const int e_local = m / tk.A, a = m - e_local * tk.A;
+  const int env = tk.idx ? tk.idx[e_local] : e_local;
+  return ((long)((long)t * tk.E + env) * tk.A + a) / tk.xshare;
+}
+
+// NB = K padded to 16-input batches; NTW = 32-feature output tiles per wave (tiles w, w+4, w+8)
+template <int NB, int NTW>
+__global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // row-major input only: XS[32][ldx]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
+  const int K = tk.K, N = tk.N;
+  const int ldx = 16 * NB + 1;
+  const int ntile_n = (N + 31) / 32;
+
+  // ---- resident weight slice: wreg[tw][b][s] = W[16b + 2s + h][32*(w + 4tw) + j]
+  float wreg[NTW][NB][8];
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw) {
+    const int col = 32 * (w + 4 * tw) + j;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int k = 16 * b + 2 * s + h;
+        wreg[tw][b][s] = (k < K && col < N) ? tk.w[(long)k * tk.ldw + col] : 0.0f;
+      }
+  }
+  if (tk.x_rowmajor) {
+    for (int i = tid; i < 32 * ldx; i += 256) lds[i] = 0.0f;
+    __syncthreads();
+  }
+
+  const int ntiles = tk.rows / 32;
+  for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+    const float* xb;  // B operand base: x[row j][k + h] at xb[k * kstride]
+    int kstride;
+    if (tk.x_rowmajor) {
+      __syncthreads();  // previous tile's readers done
+      // stage 32 gathered rows: 8 threads per row, dword pieces (immediate offsets)
+      const int srow = tid >> 3, l8 = tid & 7;
+      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * K + l8;
+      float* xs = lds + srow * ldx + l8;
+      const int nfull = K >> 3;
+#pragma unroll
+      for (int i = 0; i < 2 * NB; ++i) {
+        if (i < nfull) xs[8 * i] = xrow[8 * i];
+        else if (i == nfull && l8 + 8 * i < K) xs[8 * i] = xrow[8 * i];
+      }
+      __syncthreads();
+      xb = lds + j * ldx + h;
+      kstride = 1;
+    } else {
+      xb = tk.x + ((long)it * K + h) * 32 + j;  // T32: elem(row j, k) at (it*K + k)*32 + j
+      kstride = 32;
+    }
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int fb = 32 * (w + 4 * tw) + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fb + (r & 3) + 8 * (r >> 2);
+        acc[tw][r] = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
+      }
+    }
+    // B operands one batch ahead (LDS or L2/HBM latency behind the MFMAs of the previous batch)
+    float xo[2][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xo[0][s] = (2 * s + h < K) ? xb[(2 * s) * kstride] : 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int k = 16 * (b + 1) + 2 * s;
+          xo[(b + 1) & 1][s] = (k + h < K) ? xb[(long)k * kstride] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw) {
+        if (w + 4 * tw < ntile_n) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) acc[tw] = MFMA32(wreg[tw][b][s], xo[b & 1][s], acc[tw]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: activation, optional relu-mask gate, coalesced T32 store
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int fb = 32 * (w + 4 * tw) + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fb + (r & 3) + 8 * (r >> 2);
+        if (f < N) {
+          float v = acc[tw][r];
+          if (tk.relu) v = fmaxf(v, 0.0f);
+          const long o = ((long)it * N + f) * 32 + j;
+          if (tk.gate != nullptr) v = (tk.gate[o] > 0.0f) ? v : 0.0f;
+          tk.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+struct XtyTask {
+  const float* x;      // T32 (rows x K) or row-major gather source
+  int x_rowmajor;
+  const int32_t* idx;
+  int Rm, E, A, xshare;
+  const float* y;      // T32 (rows x N)
+  int K, N, rows;
+  float* slab;         // (gridDim.x, slab_stride): [dW (K x N row-major) | db (N)]
+  long slab_stride;
+  int want_bias;
+};
+
+// KT = K tiles of 32, NTW = N tiles per wave (n-tiles w, w+4, w+8)
+template <int KT, int NTW>
+__global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LD = 33;
+  const int K = tk.K, N = tk.N;
+  float* const XT = lds;                  // [32*KT][33] x^T tile (feature-major)
+  float* const YT = lds + 32 * KT * LD;   // [N pad 32][33]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
+  const int ntile_n = (N + 31) / 32;
+  const int npad = ntile_n * 32;
+
+  f32x16 acc[KT][NTW];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][tw][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};  // thread handles columns tid and tid + 256
+
+  for (int i = tid; i < (32 * KT + npad) * LD; i += 256) lds[i] = 0.0f;
+  __syncthreads();
+
+  const int ntiles = tk.rows / 32;
+  for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+    __syncthreads();
+    // ---- stage y^T (T32 source is already feature-major: contiguous 32-row runs)
+    for (int i = tid; i < N * 32; i += 256) {
+      const int f = i >> 5, r = i & 31;
+      YT[f * LD + r] = tk.y[((long)it * N) * 32 + i];
+    }
+    if (tk.x_rowmajor) {
+      const int srow = tid >> 3, l8 = tid & 7;
+      const float* xrow = tk.x + ((long)0) * 0;
+      {
+        DenseTask g;
+        g.Rm = tk.Rm; g.E = tk.E; g.A = tk.A; g.xshare = tk.xshare; g.idx = tk.idx;
+        xrow = tk.x + gather_row(g, it * 32 + srow) * K;
+      }
+      for (int k = l8; k < K; k += 8) XT[k * LD + srow] = xrow[k];
+    } else {
+      for (int i = tid; i < K * 32; i += 256) {
+        const int f = i >> 5, r = i & 31;
+        XT[f * LD + r] = tk.x[((long)it * K) * 32 + i];
+      }
+    }
+    __syncthreads();
+    // ---- dW[k][n] += sum_rows x[row][k] * y[row][n]
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      if (w + 4 * tw < ntile_n) {
+        const float* eb = YT + (32 * (w + 4 * tw) + j) * LD + h;
+        float bz[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bz[s] = eb[2 * s];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const float* ea = XT + (32 * kt + j) * LD + h;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc[kt][tw] = MFMA32(ea[2 * s], bz[s], acc[kt][tw]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (tk.want_bias) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int n = tid + 256 * u;
+        if (n < N) {
+          float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = YT[n * LD + 16 * c + r];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { s0 += v[r]; s1 += v[r + 1]; }
+          }
+          bsum[u] += s0 + s1;
+        }
+      }
+    }
+  }
+  float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n = 32 * (w + 4 * tw) + j;
+        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r];
+      }
+  if (tk.want_bias) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = tid + 256 * u;
+      if (n < N) slab[(long)K * N + n] = bsum[u];
+    }
+  }
+}
+
+template <int NB, int NTW>
+int launch_dense(const DenseTask& tk, hipStream_t s) {
+  const size_t lb = tk.x_rowmajor ? (size_t)32 * (16 * NB + 1) * sizeof(float) : 0;
+  if (lb > 0)
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_kernel<NB, NTW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+  int blocks = tk.rows / 32;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL((rec_dense_kernel<NB, NTW>), dim3(blocks), dim3(256), lb, s, tk);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+template <int KT, int NTW>
+int launch_xty(const XtyTask& tk, int n_slab, hipStream_t s) {
+  const int npad = ((tk.N + 31) / 32) * 32;
+  const size_t lb = (size_t)(32 * KT + npad) * 33 * sizeof(float);
+  MAVA_ARG_CHECK(lb <= 163840, 8, "mava_rec_xty_f32: %zu bytes of LDS needed", lb);
+  MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_xty_kernel<KT, NTW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+  hipLaunchKernelGGL((rec_xty_kernel<KT, NTW>), dim3(n_slab), dim3(256), lb, s, tk);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+}  // namespace
+
+extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+                                  int x_share, const float* w, int ldw, const float* bias, const float* gate,
+                                  float* y, int K, int N, int rows, int relu, hipStream_t s) {
+  MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384 && ldw >= N, 0,
+                 "mava_rec_dense_f32: K=%d N=%d ldw=%d unsupported (K, N <= 384)", K, N, ldw);
+  MAVA_ARG_CHECK(rows >= 0 && rows % 32 == 0, 1, "mava_rec_dense_f32: rows=%d must be a multiple of 32", rows);
+  if (rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(x && w && y, 2, "mava_rec_dense_f32: null pointer argument");
+  MAVA_ARG_CHECK(!x_rowmajor || (Rm >= 1 && A >= 1 && E >= 1 && x_share >= 1 && rows % Rm == 0), 3,
+                 "mava_rec_dense_f32: bad gather description Rm=%d E=%d A=%d", Rm, E, A);
+  DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, w, ldw, bias, gate, y, K, N, rows, relu};
+  const int nb = (K + 15) / 16;
+  const int ntw = ((N + 31) / 32 + 3) / 4;  // n-tiles per wave
+  MAVA_ARG_CHECK(nb * ntw * 8 <= 192, 4, "mava_rec_dense_f32: weight slice of %d registers does not fit (K=%d N=%d)",
+                 nb * ntw * 8, K, N);
+#define DENSE_CASE(NBv, NTWv) \
+  if (nb <= NBv && ntw == NTWv) return launch_dense<NBv, NTWv>(tk, s)
+  DENSE_CASE(2, 1); DENSE_CASE(4, 1); DENSE_CASE(6, 1); DENSE_CASE(8, 1); DENSE_CASE(12, 1); DENSE_CASE(18, 1);
+  DENSE_CASE(24, 1); DENSE_CASE(8, 2); DENSE_CASE(12, 2); DENSE_CASE(8, 3);
+#undef DENSE_CASE
+  mava_set_error("mava_rec_dense_f32: shape K=%d N=%d is not instantiated", K, N);
+  return MAVA_EARG(9);
+}
+
+extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
+                                const float* y, int K, int N, int rows, int want_bias, float* slab,
+                                long slab_stride, int n_slab, hipStream_t s) {
+  MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384, 0, "mava_rec_xty_f32: K=%d N=%d unsupported", K, N);
+  MAVA_ARG_CHECK(rows >= 32 && rows % 32 == 0 && n_slab >= 1 && n_slab <= 1024, 1,
+                 "mava_rec_xty_f32: rows=%d n_slab=%d", rows, n_slab);
+  MAVA_ARG_CHECK(slab_stride >= (long)K * N + (want_bias ? N : 0), 2, "mava_rec_xty_f32: slab_stride too small");
+  MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
+  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, y, K, N, rows, slab, slab_stride, want_bias};
+  const int kt = (K + 31) / 32;
+  const int ntw = ((N + 31) / 32 + 3) / 4;
+  MAVA_ARG_CHECK(kt * ntw <= 12, 4, "mava_rec_xty_f32: %d accumulator tiles per wave do not fit (K=%d N=%d)", kt * ntw, K, N);
+#define XTY_CASE(KTv, NTWv) \
+  if (kt <= KTv && ntw == NTWv) return launch_xty<KTv, NTWv>(tk, n_slab, s)
+  XTY_CASE(1, 1); XTY_CASE(2, 1); XTY_CASE(3, 1); XTY_CASE(4, 1); XTY_CASE(6, 1); XTY_CASE(9, 1); XTY_CASE(12, 1);
+  XTY_CASE(4, 2); XTY_CASE(6, 2); XTY_CASE(4, 3);
+#undef XTY_CASE
+  mava_set_error("mava_rec_xty_f32: shape K=%d N=%d is not instantiated", K, N);
+  return MAVA_EARG(9);
+}

@@ -28,12 +28,15 @@ class MLPTorso:
         self.layer_sizes = list(layer_sizes)
         self.activation = activation
         self.use_layer_norm = use_layer_norm
-        if self.layer_sizes != [HIDDEN, HIDDEN] or activation != "relu" or use_layer_norm:
+        if self.layer_sizes not in ([HIDDEN, HIDDEN], [HIDDEN]) or activation != "relu" or use_layer_norm:
             raise NotImplementedError(
-                "mava_amd's fused MLP kernels implement layer_sizes=[128,128], activation=relu, "
-                f"use_layer_norm=False (network/mlp.yaml defaults); got {self.layer_sizes}, {activation}, "
-                f"layer_norm={use_layer_norm}"
+                "mava_amd's kernels implement layer_sizes=[128,128] (network/mlp.yaml) or [128] (network/rnn.yaml), "
+                f"activation=relu, use_layer_norm=False; got {self.layer_sizes}, {activation}, layer_norm={use_layer_norm}"
             )
+
+    def require(self, layer_sizes) -> None:
+        if self.layer_sizes != list(layer_sizes):
+            raise NotImplementedError(f"this network needs a torso with layer_sizes={list(layer_sizes)}, got {self.layer_sizes}")
 
 
 class DiscreteActionHead:
@@ -131,6 +134,7 @@ class FeedForwardActor(_FeedForwardNet):
 
     def __init__(self, torso: MLPTorso, action_head: DiscreteActionHead, obs_dim: int):
         super().__init__(obs_dim, action_head.action_dim)
+        torso.require([HIDDEN, HIDDEN])
         self.torso, self.action_head = torso, action_head
 
     def _assemble(self, torso, head):
@@ -157,6 +161,7 @@ class FeedForwardValueNet(_FeedForwardNet):
 
     def __init__(self, torso: MLPTorso, centralised_critic: bool, input_dim: int):
         super().__init__(input_dim, 1)
+        torso.require([HIDDEN, HIDDEN])
         self.torso, self.centralised_critic = torso, centralised_critic
 
     def _assemble(self, torso, head):

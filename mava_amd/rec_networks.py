@@ -1,0 +1,201 @@
+"""Recurrent networks behind the reference's module names (mava/networks.py:238-331: ScannedRNN,
+RecurrentActor, RecurrentValueNet) and their sequence forward / backward as a chain of HIP kernels.
+
+Flat parameter layout (float32, one contiguous vector per network):
+    [Wpre (din,128) | bpre | Wi (128,384 = ir|iz|in) | bi (384) | Wh (128,384 = hr|hz|hn) | bhn (128)
+     | Wpost (128,128) | bpost | Whead (128,n_out) | bhead]
+The Flax-shaped tree exposed to callers holds VIEWS of that vector:
+    params/pre_torso/Dense_0, params/ScannedRNN_0/GRUCell_0/{ir,iz,in,hr,hz,hn}, params/post_torso/Dense_0,
+    params/action_head/Dense_0 (actor) or params/Dense_0 (critic).
+
+Sequence batch convention (rec_mappo.py:334-365: minibatches are env slices, all T steps): rows are
+time-major, row = t*Rm + m with m = local_env*A + agent; Rm must be a multiple of 32.  Activations live in
+the kernels' T32 tile layout inside a RecWorkspace.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import check, lib, ptr, stream_ptr
+from .distributions import Categorical
+from .networks import DiscreteActionHead, MLPTorso, _orthogonal_
+
+H = 128
+G3 = 3 * H
+
+
+def rec_segments(din: int, n_out: int):
+    segs, off = [], 0
+    for name, shape in (("Wpre", (din, H)), ("bpre", (H,)), ("Wi", (H, G3)), ("bi", (G3,)), ("Wh", (H, G3)), ("bhn", (H,)),
+                        ("Wpost", (H, H)), ("bpost", (H,)), ("Whead", (H, n_out)), ("bhead", (n_out,))):
+        segs.append((name, shape, off))
+        off += math.prod(shape)
+    return segs, off
+
+
+class RecWorkspace:
+    """Activation buffers (T32) for one sequence batch of `rows` = T*Rm row-steps; shared by actor and critic."""
+
+    def __init__(self, rows: int, n_out_max: int, device, training: bool = True):
+        f = lambda n: torch.empty(rows * n, device=device)
+        self.rows = rows
+        self.xpre, self.gi, self.hs, self.post, self.y = f(H), f(G3), f(H), f(H), f(n_out_max)
+        if training:
+            self.hprev, self.saved = f(H), f(4 * H)
+            self.dy, self.dpost, self.dh_out, self.dgi, self.dgh, self.dxpre = f(n_out_max), f(H), f(H), f(G3), f(G3), f(H)
+            self.loss_partials = torch.zeros((64, 2), device=device)
+
+
+class _RecurrentNet:
+    head_scale = 1.0
+
+    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128):
+        if hidden_state_dim != H:
+            raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
+        self.din, self.n_out = int(din), int(n_out)
+        self.segments, self.num_params = rec_segments(self.din, self.n_out)
+        self.off = {n: (o, s) for n, s, o in self.segments}
+
+    def seg(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o, s = self.off[name]
+        return flat[o : o + math.prod(s)].view(s)
+
+    def init_flat(self, seed: int, device=None) -> torch.Tensor:
+        """orthogonal(sqrt 2) torsos (networks.py:54), flax GRUCell defaults (lecun-normal input kernels,
+        orthogonal recurrent kernels, zero biases), orthogonal(head_scale) head."""
+        gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        flat = torch.zeros(self.num_params, dtype=torch.float32)
+        _orthogonal_(self.seg(flat, "Wpre"), math.sqrt(2.0), gen)
+        self.seg(flat, "Wi").copy_(torch.randn((H, G3), generator=gen) / math.sqrt(H))
+        for g in range(3):
+            blk = torch.empty(H, H)
+            _orthogonal_(blk, 1.0, gen)
+            self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(blk)
+        _orthogonal_(self.seg(flat, "Wpost"), math.sqrt(2.0), gen)
+        _orthogonal_(self.seg(flat, "Whead"), self.head_scale, gen)
+        return flat.to(device) if device is not None else flat
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        ex = (lambda v: v.expand(*lead, *v.shape)) if lead else (lambda v: v)
+        Wi, bi, Wh = self.seg(flat, "Wi"), self.seg(flat, "bi"), self.seg(flat, "Wh")
+        cell = {
+            "ir": {"kernel": ex(Wi[:, :H]), "bias": ex(bi[:H])},
+            "iz": {"kernel": ex(Wi[:, H : 2 * H]), "bias": ex(bi[H : 2 * H])},
+            "in": {"kernel": ex(Wi[:, 2 * H :]), "bias": ex(bi[2 * H :])},
+            "hr": {"kernel": ex(Wh[:, :H])},
+            "hz": {"kernel": ex(Wh[:, H : 2 * H])},
+            "hn": {"kernel": ex(Wh[:, 2 * H :]), "bias": ex(self.seg(flat, "bhn"))},
+        }
+        tree = {
+            "pre_torso": {"Dense_0": {"kernel": ex(self.seg(flat, "Wpre")), "bias": ex(self.seg(flat, "bpre"))}},
+            "ScannedRNN_0": {"GRUCell_0": cell},
+            "post_torso": {"Dense_0": {"kernel": ex(self.seg(flat, "Wpost")), "bias": ex(self.seg(flat, "bpost"))}},
+        }
+        head = {"kernel": ex(self.seg(flat, "Whead")), "bias": ex(self.seg(flat, "bhead"))}
+        tree.update(self._head_tree(head))
+        return {"params": tree}
+
+    # ------------------------------------------------------------------------------------- kernels
+    def forward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, h0, h0_t32, idx, T, Rm, E, A,
+                         training: bool) -> torch.Tensor:
+        """Runs the network over a time-major sequence batch; returns T32 outputs (ws.y).  x_ext is the external
+        row-major (T, E, A/x_share.., din) tensor, done_ext (T, E, A) u8 the flags entering each step."""
+        rows = T * Rm
+        L = lib()
+        s = stream_ptr()
+        W = lambda n: ptr(self.seg(flat, n))
+        check(L.mava_rec_dense_f32(ptr(x_ext), 1, ptr(idx), Rm, E, A, x_share, W("Wpre"), H, W("bpre"), None, ptr(ws.xpre),
+                                   self.din, H, rows, 1, s), "rec_dense(pre)")
+        check(L.mava_rec_dense_f32(ptr(ws.xpre), 0, None, 0, 0, 0, 1, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H, G3, rows, 0, s),
+              "rec_dense(gi)")
+        check(L.mava_gru_scan_fwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"), ptr(ws.gi),
+                                      ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s),
+              "gru_scan_fwd")
+        check(L.mava_rec_dense_f32(ptr(ws.hs), 0, None, 0, 0, 0, 1, W("Wpost"), H, W("bpost"), None, ptr(ws.post), H, H, rows, 1, s),
+              "rec_dense(post)")
+        check(L.mava_rec_dense_f32(ptr(ws.post), 0, None, 0, 0, 0, 1, W("Whead"), self.n_out, W("bhead"), None, ptr(ws.y), H,
+                                   self.n_out, rows, 0, s), "rec_dense(head)")
+        return ws.y
+
+    def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
+                          accumulate: bool) -> None:
+        """BPTT from ws.dy (T32 d loss / d outputs) to the flat gradient `grad_out` (same layout as `flat`)."""
+        rows = T * Rm
+        L = lib()
+        s = stream_ptr()
+        n_out = self.n_out
+        # transposed weights for the dX = dY W^T products (tiny, re-materialised per call)
+        WheadT = self.seg(flat, "Whead").t().contiguous()
+        WpostT = self.seg(flat, "Wpost").t().contiguous()
+        WiT = self.seg(flat, "Wi").t().contiguous()
+        d = lambda k, N, x, w, ldw, gate, y: check(
+            L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, ptr(w), ldw, None, ptr(gate), ptr(y), k, N, rows, 0, s), "rec_dense(bwd)")
+        d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
+        d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
+        check(L.mava_gru_scan_bwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved), ptr(ws.hprev),
+                                      ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s), "gru_scan_bwd")
+        d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
+
+        def xty(x, x_rowmajor, K, N, y, wname, bname, xs=1, bias_slice=None):
+            n_slab = slabs.shape[0]
+            check(L.mava_rec_xty_f32(ptr(x), x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, ptr(y), K, N, rows, 1,
+                                     ptr(slabs), slabs.shape[1], n_slab, s), f"rec_xty({wname})")
+            ow, sw = self.off[wname]
+            ops.slab_reduce(slabs, K * N, grad_out[ow : ow + K * N], accumulate=accumulate)
+            if bname is not None:
+                ob, sb = self.off[bname]
+                nb = math.prod(sb)
+                src = slabs[:, K * N :] if bias_slice is None else slabs[:, K * N + bias_slice :]
+                # strided view of the slab tail: reduce through the generic reducer on a contiguous copy of the tail
+                tail = src[:, :nb].contiguous()
+                ops.slab_reduce(tail, nb, grad_out[ob : ob + nb], accumulate=accumulate)
+
+        xty(ws.post, 0, H, n_out, ws.dy, "Whead", "bhead")
+        xty(ws.hs, 0, H, H, ws.dpost, "Wpost", "bpost")
+        xty(ws.xpre, 0, H, G3, ws.dgi, "Wi", "bi")
+        xty(ws.hprev, 0, H, G3, ws.dgh, "Wh", "bhn", bias_slice=2 * H)  # db_hn = colsum of the n-part of dgh
+        xty(x_ext, 1, self.din, H, ws.dxpre, "Wpre", "bpre", xs=x_share)
+
+
+class RecurrentActor(_RecurrentNet):
+    """mava/networks.py:269-294 with DiscreteActionHead (head init orthogonal(0.01))."""
+
+    head_scale = 0.01
+
+    def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head: DiscreteActionHead, obs_dim: int,
+                 hidden_state_dim: int = 128):
+        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim)
+
+    def _head_tree(self, head):
+        return {"action_head": {"Dense_0": head}}
+
+
+class RecurrentValueNet(_RecurrentNet):
+    """mava/networks.py:297-331 (head Dense(1) init orthogonal(1.0))."""
+
+    head_scale = 1.0
+
+    def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, centralised_critic: bool, input_dim: int,
+                 hidden_state_dim: int = 128):
+        super().__init__(input_dim, 1, hidden_state_dim)
+        self.centralised_critic = centralised_critic
+
+    def _head_tree(self, head):
+        return {"Dense_0": head}
+
+
+def t32_to_rows(src: torch.Tensor, N: int, rows: int) -> torch.Tensor:
+    out = torch.empty((rows, N), device=src.device)
+    check(lib().mava_t32_convert_f32(ptr(src), N, rows, 0, ptr(out), stream_ptr()), "t32_convert")
+    return out
+
+
+def rows_to_t32(src: torch.Tensor) -> torch.Tensor:
+    rows, N = src.shape
+    out = torch.empty(rows * N, device=src.device)
+    check(lib().mava_t32_convert_f32(ptr(src.contiguous()), N, rows, 1, ptr(out), stream_ptr()), "t32_convert")
+    return out

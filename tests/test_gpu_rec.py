@@ -1,0 +1,206 @@
+"""GPU parity of the recurrent path (rec_ippo / rec_mappo kernels) against oracle/rec_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rec_oracle as ro
+from tests.conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def _to_t32(a):
+    """(rows, N) row-major numpy -> T32 flat numpy."""
+    rows, N = a.shape
+    return a.reshape(rows // 32, 32, N).transpose(0, 2, 1).reshape(-1).copy()
+
+
+def _from_t32(flat, rows, N):
+    return np.asarray(flat).reshape(rows // 32, N, 32).transpose(0, 2, 1).reshape(rows, N)
+
+
+@pytest.mark.parametrize("K,N,relu,gated", [(128, 384, False, False), (128, 128, True, False), (128, 13, False, False),
+                                             (384, 128, False, True), (5, 128, False, True), (155, 128, True, False)])
+def test_rec_dense_t32(dev, K, N, relu, gated):
+    from mava_amd._lib import check, lib, ptr, stream_ptr
+
+    rng = np.random.default_rng(K + N)
+    rows = 96
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    g = rng.standard_normal((rows, N)).astype(np.float32)
+    y = torch.zeros(rows * N, device=dev)
+    xt, wt, bt, gt = _t(_to_t32(x), dev), _t(w, dev), _t(b, dev), _t(_to_t32(g), dev)
+    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), K, N,
+                                   rows, int(relu), stream_ptr()), "dense")
+    torch.cuda.synchronize()
+    want = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        want = np.maximum(want, 0)
+    if gated:
+        want = want * (g > 0)
+    assert_close(_from_t32(y.cpu().numpy(), rows, N), want, 1e-5, "dense")
+
+
+def test_rec_dense_rowmajor_gather_and_xty(dev):
+    from mava_amd._lib import check, lib, ptr, stream_ptr
+    from mava_amd import ops
+
+    rng = np.random.default_rng(3)
+    T, E, A, K, N = 3, 20, 4, 70, 128
+    Em = 8  # minibatch envs
+    Rm, rows = Em * A, T * Em * A
+    obs = rng.standard_normal((T, E, A, K)).astype(np.float32)
+    idx = rng.permutation(E)[:Em].astype(np.int32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y = torch.zeros(rows * N, device=dev)
+    check(lib().mava_rec_dense_f32(ptr(_t(obs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, 1, ptr(_t(w, dev)), N, ptr(_t(b, dev)), None,
+                                   ptr(y), K, N, rows, 1, stream_ptr()), "dense gather")
+    xg = obs[:, idx].reshape(rows, K).astype(np.float64)  # time-major, env-major inside a step
+    want = np.maximum(xg @ w.astype(np.float64) + b, 0)
+    got = _from_t32(y.cpu().numpy(), rows, N)
+    assert_close(got, want, 1e-5, "dense gather")
+    # shared input rows (global state stored once per env)
+    gs = rng.standard_normal((T, E, K)).astype(np.float32)
+    check(lib().mava_rec_dense_f32(ptr(_t(gs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, A, ptr(_t(w, dev)), N, ptr(_t(b, dev)), None,
+                                   ptr(y), K, N, rows, 0, stream_ptr()), "dense gather shared")
+    want2 = np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64) @ w.astype(np.float64) + b
+    assert_close(_from_t32(y.cpu().numpy(), rows, N), want2, 1e-5, "dense gather shared")
+    # X^T Y with both input kinds
+    dy = rng.standard_normal((rows, N)).astype(np.float32)
+    slab = torch.zeros((5, K * N + N), device=dev)
+    check(lib().mava_rec_xty_f32(ptr(_t(obs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, 1, ptr(_t(_to_t32(dy), dev)), K, N, rows, 1,
+                                 ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
+    out = torch.zeros(K * N + N, device=dev)
+    ops.slab_reduce(slab, K * N + N, out)
+    got = out.cpu().numpy()
+    assert_close(got[: K * N].reshape(K, N), xg.T @ dy.astype(np.float64), 1e-5, "xty dW")
+    assert_close(got[K * N :], dy.astype(np.float64).sum(0), 1e-5, "xty db")
+    x2 = rng.standard_normal((rows, 128)).astype(np.float32)
+    dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
+    slab = torch.zeros((3, 128 * 384 + 384), device=dev)
+    check(lib().mava_rec_xty_f32(ptr(_t(_to_t32(x2), dev)), 0, None, 0, 0, 0, 1, ptr(_t(_to_t32(dy2), dev)), 128, 384, rows, 1,
+                                 ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
+    out = torch.zeros(128 * 384 + 384, device=dev)
+    ops.slab_reduce(slab, out.numel(), out)
+    assert_close(out.cpu().numpy()[: 128 * 384].reshape(128, 384), x2.astype(np.float64).T @ dy2.astype(np.float64), 1e-5, "xty t32")
+
+
+def _seq_case(rng, T, E, A, Em, din, nA, shared):
+    obs = rng.standard_normal((T, E, 1 if shared else A, din)).astype(np.float32)
+    done = rng.random((T, E)) < 0.15
+    done = np.repeat(done[:, :, None], A, 2)
+    h0 = (rng.standard_normal((E, A, 128)) * 0.5).astype(np.float32)
+    idx = rng.permutation(E)[:Em].astype(np.int32)
+    return obs, done, h0, idx
+
+
+def _gather(x, idx, A, shared):
+    """external (T,E,A|1,...) -> (T, Em*A, ...) time-major minibatch rows"""
+    g = x[:, idx]
+    if shared:
+        g = np.repeat(g, A, 2)
+    return g.reshape(g.shape[0], g.shape[1] * g.shape[2], *g.shape[3:])
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_recurrent_forward_matches_oracle(dev, shared):
+    from mava_amd.networks import DiscreteActionHead, MLPTorso
+    from mava_amd.rec_networks import RecurrentActor, RecWorkspace, t32_to_rows
+
+    rng = np.random.default_rng(11)
+    T, E, A, Em, din, nA = 9, 12, 4, 8, 37, 6
+    obs, done, h0, idx = _seq_case(rng, T, E, A, Em, din, nA, shared)
+    net = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
+    flat = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
+    flat[net.off["bi"][0] : net.off["bi"][0] + 384] = rng.standard_normal(384) * 0.1
+    flat[net.off["bhn"][0] : net.off["bhn"][0] + 128] = rng.standard_normal(128) * 0.1
+    assert flat.size == net.num_params == ro.rec_param_count(din, nA)
+    Rm = Em * A
+    ws = RecWorkspace(T * Rm, nA, dev)
+    y = net.forward_sequence(_t(flat, dev), ws, _t(obs, dev), A if shared else 1, _t(done, dev).view(torch.uint8), _t(h0, dev), False,
+                             _t(idx, dev), T, Rm, E, A, training=True)
+    torch.cuda.synchronize()
+    want, hs_in, h_last = ro.rec_forward(flat, din, nA, _gather(obs, idx, A, shared), _gather(done, idx, A, False),
+                                         _gather(h0[None], idx, A, False)[0])
+    got = t32_to_rows(y, nA, T * Rm).cpu().numpy().reshape(T, Rm, nA)
+    assert_close(got, want, 1e-5, "recurrent logits")
+    hs = t32_to_rows(ws.hs, 128, T * Rm).cpu().numpy().reshape(T, Rm, 128)
+    assert_close(hs[-1], h_last, 1e-5, "final hidden state")
+
+
+@pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13)])
+def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
+    from mava_amd import ops
+    from mava_amd._lib import check, lib, ptr, stream_ptr
+    from mava_amd.networks import DiscreteActionHead, MLPTorso
+    from mava_amd.rec_networks import RecurrentActor, RecurrentValueNet, RecWorkspace, t32_to_rows
+
+    rng = np.random.default_rng(T + nA)
+    obs, done, h0, idx = _seq_case(rng, T, E, A, Em, din, nA, False)
+    Rm, rows = Em * A, T * Em * A
+    actor = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
+    critic = RecurrentValueNet(MLPTorso([128]), MLPTorso([128]), False, din)
+    fa = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
+    fc = ro.init_rec(rng, din, 1, 1.0).astype(np.float32)
+    mask = rng.random((T, E, A, nA)) > 0.25
+    action = rng.integers(0, nA, (T, E, A)).astype(np.int32)
+    np.put_along_axis(mask, action[..., None].astype(np.int64), True, -1)
+    go = lambda x: _gather(x, idx, A, False)
+    y, _, _ = ro.rec_forward(fa, din, nA, go(obs), go(done), go(h0[None])[0])
+    z = np.where(go(mask), y, ro.F32_MIN)
+    lsm = z - (z.max(-1, keepdims=True) + np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)))
+    lp_now = np.take_along_axis(lsm, go(action)[..., None].astype(np.int64), -1)[..., 0]
+    old_lp = np.zeros((T, E, A), np.float32)
+    old_lp[:, idx] = (lp_now + rng.standard_normal(lp_now.shape) * 0.25).reshape(T, Em, A)
+    adv = (rng.standard_normal((T, E, A)) * 2 + 0.3).astype(np.float32)
+    v_now, _, _ = ro.rec_forward(fc, din, 1, go(obs), go(done), go(h0[None])[0])
+    old_v = np.zeros((T, E, A), np.float32)
+    tgt = np.zeros((T, E, A), np.float32)
+    old_v[:, idx] = (v_now[..., 0] + rng.standard_normal(lp_now.shape) * 0.2).reshape(T, Em, A)
+    tgt[:, idx] = (v_now[..., 0] + rng.standard_normal(lp_now.shape)).reshape(T, Em, A)
+
+    ws = RecWorkspace(rows, max(nA, 1), dev)
+    d = lambda a, dt=None: _t(a, dev, dt)
+    idx_d, done_d, h0_d, obs_d = d(idx), d(done).view(torch.uint8), d(h0), d(obs)
+    slabs = torch.zeros((4, 128 * 384 + 384 + 8), device=dev)
+    # ---- actor
+    fa_d = d(fa)
+    actor.forward_sequence(fa_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
+    flat_rows = (torch.arange(T, device=dev)[:, None] * E + idx_d[None, :].long()).reshape(-1).to(torch.int32)
+    stats = ops.adv_stats(d(adv).view(-1), flat_rows, 0, T * Em, A)
+    check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(d(mask).view(torch.uint8)), ptr(d(action)),
+                                        ptr(d(old_lp)), ptr(d(adv)), ptr(stats), stats.shape[0], 0.2, 0.01, ptr(ws.dy),
+                                        ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "actor loss")
+    ga = torch.zeros(actor.num_params, device=dev)
+    actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False)
+    torch.cuda.synchronize()
+    tot, la, ent, g = ro.rec_actor_loss_grad(fa, din, nA, go(obs), go(done), go(h0[None])[0], go(mask), go(action), go(old_lp),
+                                             go(adv), 0.2, 0.01)
+    lsum = ws.loss_partials.sum(0).cpu().numpy()
+    assert_close(lsum, np.array([la, ent]), 1e-5, "actor loss / entropy", scale=1.0)
+    assert_close(ga.cpu().numpy(), g, 1e-4, "recurrent actor gradient")  # north_star: PPO gradients 1e-4
+    for name in ("Wpre", "Wi", "Wh", "bhn", "Whead"):
+        o, s = actor.off[name]
+        n = int(np.prod(s))
+        assert_close(ga.cpu().numpy()[o : o + n], g[o : o + n], 1e-4, f"actor grad {name}")
+    # ---- critic
+    fc_d = d(fc)
+    critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
+    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx_d), ptr(ws.y), ptr(d(old_v)), ptr(d(tgt)), 0.2, 0.5, ptr(ws.dy),
+                                         ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
+    gc = torch.zeros(critic.num_params, device=dev)
+    critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False)
+    torch.cuda.synchronize()
+    tot, vl, g = ro.rec_critic_loss_grad(fc, din, go(obs), go(done), go(h0[None])[0], go(old_v), go(tgt), 0.2, 0.5)
+    assert_close(ws.loss_partials.sum(0).cpu().numpy()[:1], np.array([vl]), 1e-5, "value loss", scale=1.0)
+    assert_close(gc.cpu().numpy(), g, 1e-4, "recurrent critic gradient")

@@ -61,6 +61,8 @@ def test_param_tree_is_a_view_of_the_flat_buffer():
     assert set(ctree["params"]) == {"torso", "Dense_0"} and ctree["params"]["Dense_0"]["kernel"].shape == (128, 1)
     with pytest.raises(NotImplementedError):
         MLPTorso([64, 64])
+    with pytest.raises(NotImplementedError):
+        FeedForwardActor(MLPTorso([128]), DiscreteActionHead(5), 70)
 
 
 def test_final_step_metrics():

@@ -63,7 +63,10 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
     y = torch.zeros(rows * N, device=dev)
-    check(lib().mava_rec_dense_f32(ptr(_t(obs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, 1, ptr(_t(w, dev)), N, ptr(_t(b, dev)), None,
+    # NB: every device tensor handed to the C ABI is kept alive in a named variable (a temporary would be
+    # freed - and its block recycled by the caching allocator - before the asynchronous kernel reads it)
+    obs_d, idx_d, w_d, b_d = _t(obs, dev), _t(idx, dev), _t(w, dev), _t(b, dev)
+    check(lib().mava_rec_dense_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), K, N, rows, 1, stream_ptr()), "dense gather")
     xg = obs[:, idx].reshape(rows, K).astype(np.float64)  # time-major, env-major inside a step
     want = np.maximum(xg @ w.astype(np.float64) + b, 0)
@@ -71,14 +74,16 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     assert_close(got, want, 1e-5, "dense gather")
     # shared input rows (global state stored once per env)
     gs = rng.standard_normal((T, E, K)).astype(np.float32)
-    check(lib().mava_rec_dense_f32(ptr(_t(gs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, A, ptr(_t(w, dev)), N, ptr(_t(b, dev)), None,
+    gs_d = _t(gs, dev)
+    check(lib().mava_rec_dense_f32(ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), K, N, rows, 0, stream_ptr()), "dense gather shared")
     want2 = np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64) @ w.astype(np.float64) + b
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want2, 1e-5, "dense gather shared")
     # X^T Y with both input kinds
     dy = rng.standard_normal((rows, N)).astype(np.float32)
+    dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(_t(obs, dev)), 1, ptr(_t(idx, dev)), Rm, E, A, 1, ptr(_t(_to_t32(dy), dev)), K, N, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, ptr(dy_d), K, N, rows, 1,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -87,8 +92,9 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     assert_close(got[K * N :], dy.astype(np.float64).sum(0), 1e-5, "xty db")
     x2 = rng.standard_normal((rows, 128)).astype(np.float32)
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
+    x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(_t(_to_t32(x2), dev)), 0, None, 0, 0, 0, 1, ptr(_t(_to_t32(dy2), dev)), 128, 384, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, ptr(dy2_d), 128, 384, rows, 1,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
@@ -127,8 +133,8 @@ def test_recurrent_forward_matches_oracle(dev, shared):
     assert flat.size == net.num_params == ro.rec_param_count(din, nA)
     Rm = Em * A
     ws = RecWorkspace(T * Rm, nA, dev)
-    y = net.forward_sequence(_t(flat, dev), ws, _t(obs, dev), A if shared else 1, _t(done, dev).view(torch.uint8), _t(h0, dev), False,
-                             _t(idx, dev), T, Rm, E, A, training=True)
+    flat_d, obs_d, done_d, h0_d, idx_d = _t(flat, dev), _t(obs, dev), _t(done, dev).view(torch.uint8), _t(h0, dev), _t(idx, dev)
+    y = net.forward_sequence(flat_d, ws, obs_d, A if shared else 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
     torch.cuda.synchronize()
     want, hs_in, h_last = ro.rec_forward(flat, din, nA, _gather(obs, idx, A, shared), _gather(done, idx, A, False),
                                          _gather(h0[None], idx, A, False)[0])
@@ -177,9 +183,10 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
     fa_d = d(fa)
     actor.forward_sequence(fa_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
     flat_rows = (torch.arange(T, device=dev)[:, None] * E + idx_d[None, :].long()).reshape(-1).to(torch.int32)
-    stats = ops.adv_stats(d(adv).view(-1), flat_rows, 0, T * Em, A)
-    check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(d(mask).view(torch.uint8)), ptr(d(action)),
-                                        ptr(d(old_lp)), ptr(d(adv)), ptr(stats), stats.shape[0], 0.2, 0.01, ptr(ws.dy),
+    adv_d, mask_d, act_d, olp_d = d(adv), d(mask).view(torch.uint8), d(action), d(old_lp)  # kept alive (see above)
+    stats = ops.adv_stats(adv_d.view(-1), flat_rows, 0, T * Em, A)
+    check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(mask_d), ptr(act_d),
+                                        ptr(olp_d), ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, ptr(ws.dy),
                                         ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "actor loss")
     ga = torch.zeros(actor.num_params, device=dev)
     actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False)
@@ -196,7 +203,8 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
     # ---- critic
     fc_d = d(fc)
     critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
-    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx_d), ptr(ws.y), ptr(d(old_v)), ptr(d(tgt)), 0.2, 0.5, ptr(ws.dy),
+    ov_d, tg_d = d(old_v), d(tgt)
+    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, ptr(ws.dy),
                                          ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
     gc = torch.zeros(critic.num_params, device=dev)
     critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False)

@@ -124,10 +124,11 @@ int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_i
  *      mava/wrappers/observation.py:41-53, jumanji.py:53-59,128-143, auto_reset_wrapper.py:88-101
  *      and episode_metrics.py:78-111.  One call = one vectorised env.step (or reset when is_reset).
  * state: step_count (E,A) i32, run_return/ep_return (E) f32, run_length/ep_length (E) i32.
- * outputs: agents_view (E,A,A+O), global_state (E,gs_tiles,A*O) with gs_tiles in {1,A},
+ * outputs: agents_view (E,A,A+O), global_state (E,gs_tiles,W) with gs_tiles in {1,A} and W = A*O (concatenated
+ * raw views, RWARE) when state_dim == 0 or W = state_dim (independent state vector, SMAX-shaped),
  * action_mask (E,A,n_actions) u8, obs_step_count (E,A) i32; transition: reward (E,A) f32,
  * done (E,A) u8, info_return (E) f32, info_length (E) i32, info_terminal (E) u8. */
-int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int time_limit,
+int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int state_dim, int time_limit,
                           uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
                           int32_t* step_count, float* run_return, int32_t* run_length,
                           float* ep_return, int32_t* ep_length, float* agents_view,
@@ -143,15 +144,17 @@ int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int 
  *      and env ids come from idx (Rm/A entries, a slice of the env permutation) or the identity. */
 
 /* Y = act(X W + b) [masked by gate > 0]; X is T32 (rows x K) or, with x_rowmajor, the external row-major
- * source gathered per batch row; W (K x N) row-major with row stride ldw; Y T32 (rows x N). */
+ * source (row stride x_ld >= K, so a call can read a column block) gathered per batch row; W (K x N)
+ * row-major with row stride ldw; Y T32 (rows x N).  accumulate: start from the existing Y (K-chunked
+ * products for inputs wider than 384). */
 int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                       int x_share, const float* w, int ldw, const float* bias, const float* gate,
-                       float* y, int K, int N, int rows, int relu, mava_stream_t s);
+                       int x_share, int x_ld, int accumulate, const float* w, int ldw, const float* bias,
+                       const float* gate, float* y, int K, int N, int rows, int relu, mava_stream_t s);
 
 /* per-block slabs of dW = X^T Y (K x N row-major) followed by db = colsum(Y) when want_bias. */
 int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                     int x_share, const float* y, int K, int N, int rows, int want_bias, float* slab,
-                     long slab_stride, int n_slab, mava_stream_t s);
+                     int x_share, int x_ld, const float* y, int K, int N, int rows, int want_bias,
+                     float* slab, long slab_stride, int n_slab, mava_stream_t s);
 
 /* GRU over T steps (flax GRUCell; hidden state zeroed where done enters the step).  gi = W_i x + b_i
  * precomputed (T32, T*Rm x 384); wh (128 x 384) = [hr|hz|hn]; outputs hs (T32, h after each step) and,

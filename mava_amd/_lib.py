@@ -48,9 +48,9 @@ _SIGNATURES = {
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
-    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, u64, u32, u32, i32] + [vp] * 15,
-    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
+    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, u32, i32] + [vp] * 15,
+    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
     "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "mava_gru_scan_bwd_f32": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, i32, vp],

@@ -24,6 +24,8 @@ struct DenseTask {
   // agent = m % A, source row = ((t * E + env) * A + agent) / xshare
   const int32_t* idx;    // (Rm / A) env ids of the minibatch, or null (identity)
   int Rm, E, A, xshare;
+  int x_ld;              // row stride (floats) of the row-major source (>= K; lets a call read a column block)
+  int accumulate;        // 1: start from the existing y (T32) instead of the bias (K-chunked products)
   const float* w;        // (K x N) row-major, row stride ldw
   int ldw;
   const float* bias;     // (N) or null
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
       __syncthreads();  // previous tile's readers done
       // stage 32 gathered rows: 8 threads per row, dword pieces (immediate offsets)
       const int srow = tid >> 3, l8 = tid & 7;
-      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * K + l8;
+      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld + l8;
       float* xs = lds + srow * ldx + l8;
       const int nfull = K >> 3;
 #pragma unroll
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = fb + (r & 3) + 8 * (r >> 2);
-        acc[tw][r] = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
+        float a0 = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
+        if (tk.accumulate && f < N) a0 += tk.y[((long)it * N + f) * 32 + j];
+        acc[tw][r] = a0;
       }
     }
     // B operands one batch ahead (LDS or L2/HBM latency behind the MFMAs of the previous batch)
@@ -147,6 +151,7 @@ struct XtyTask {
   int x_rowmajor;
   const int32_t* idx;
   int Rm, E, A, xshare;
+  int x_ld;
   const float* y;      // T32 (rows x N)
   int K, N, rows;
   float* slab;         // (gridDim.x, slab_stride): [dW (K x N row-major) | db (N)]
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
       {
         DenseTask g;
         g.Rm = tk.Rm; g.E = tk.E; g.A = tk.A; g.xshare = tk.xshare; g.idx = tk.idx;
-        xrow = tk.x + gather_row(g, it * 32 + srow) * K;
+        xrow = tk.x + gather_row(g, it * 32 + srow) * tk.x_ld;
       }
       for (int k = l8; k < K; k += 8) XT[k * LD + srow] = xrow[k];
     } else {
@@ -287,16 +292,17 @@ int launch_xty(const XtyTask& tk, int n_slab, hipStream_t s) {
 }  // namespace
 
 extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                                  int x_share, const float* w, int ldw, const float* bias, const float* gate,
-                                  float* y, int K, int N, int rows, int relu, hipStream_t s) {
+                                  int x_share, int x_ld, int accumulate, const float* w, int ldw,
+                                  const float* bias, const float* gate, float* y, int K, int N, int rows,
+                                  int relu, hipStream_t s) {
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384 && ldw >= N, 0,
                  "mava_rec_dense_f32: K=%d N=%d ldw=%d unsupported (K, N <= 384)", K, N, ldw);
   MAVA_ARG_CHECK(rows >= 0 && rows % 32 == 0, 1, "mava_rec_dense_f32: rows=%d must be a multiple of 32", rows);
   if (rows == 0) return MAVA_OK;
   MAVA_ARG_CHECK(x && w && y, 2, "mava_rec_dense_f32: null pointer argument");
-  MAVA_ARG_CHECK(!x_rowmajor || (Rm >= 1 && A >= 1 && E >= 1 && x_share >= 1 && rows % Rm == 0), 3,
-                 "mava_rec_dense_f32: bad gather description Rm=%d E=%d A=%d", Rm, E, A);
-  DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, w, ldw, bias, gate, y, K, N, rows, relu};
+  MAVA_ARG_CHECK(!x_rowmajor || (Rm >= 1 && A >= 1 && E >= 1 && x_share >= 1 && rows % Rm == 0 && x_ld >= K), 3,
+                 "mava_rec_dense_f32: bad gather description Rm=%d E=%d A=%d x_ld=%d", Rm, E, A, x_ld);
+  DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, accumulate, w, ldw, bias, gate, y, K, N, rows, relu};
   const int nb = (K + 15) / 16;
   const int ntw = ((N + 31) / 32 + 3) / 4;  // n-tiles per wave
   MAVA_ARG_CHECK(nb * ntw * 8 <= 192, 4, "mava_rec_dense_f32: weight slice of %d registers does not fit (K=%d N=%d)",
@@ -311,14 +317,15 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
 }
 
 extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
-                                const float* y, int K, int N, int rows, int want_bias, float* slab,
+                                int x_ld, const float* y, int K, int N, int rows, int want_bias, float* slab,
                                 long slab_stride, int n_slab, hipStream_t s) {
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384, 0, "mava_rec_xty_f32: K=%d N=%d unsupported", K, N);
   MAVA_ARG_CHECK(rows >= 32 && rows % 32 == 0 && n_slab >= 1 && n_slab <= 1024, 1,
                  "mava_rec_xty_f32: rows=%d n_slab=%d", rows, n_slab);
   MAVA_ARG_CHECK(slab_stride >= (long)K * N + (want_bias ? N : 0), 2, "mava_rec_xty_f32: slab_stride too small");
   MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
-  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, y, K, N, rows, slab, slab_stride, want_bias};
+  MAVA_ARG_CHECK(!x_rowmajor || x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
+  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, slab, slab_stride, want_bias};
   const int kt = (K + 31) / 32;
   const int ntw = ((N + 31) / 32 + 3) / 4;
   MAVA_ARG_CHECK(kt * ntw <= 12, 4, "mava_rec_xty_f32: %d accumulator tiles per wave do not fit (K=%d N=%d)", kt * ntw, K, N);

@@ -25,6 +25,8 @@ constexpr uint32_t ENV_STREAM = 0x454E5653u;  // "ENVS"
 struct SynthArgs {
   int E, A, O, nA;
   int gs_tiles;       // 1: global_state (E, A*O) shared by the agents; A: (E, A, A*O) tiled copy
+  int S;              // 0: global_state = concatenated raw views (RWARE); > 0: an independent S-feature state
+                      //    vector per env (SMAX-shaped: mava/wrappers/jaxmarl.py:326-373 world state)
   int time_limit;
   uint32_t seed_lo, seed_hi;
   uint32_t t;         // global step counter (unique per call)
@@ -66,7 +68,8 @@ __device__ __forceinline__ float synth_raw_feature(uint32_t ent, int f, const Sy
 __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
   const uint32_t E = a.E, A = a.A, O = a.O, W = A + O;
   const uint32_t n_av = E * A * W;
-  const uint32_t n_gs = E * (uint32_t)a.gs_tiles * A * O;
+  const uint32_t gsw = a.S > 0 ? (uint32_t)a.S : A * O;  // width of one global-state row
+  const uint32_t n_gs = E * (uint32_t)a.gs_tiles * gsw;
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
   if (gid < n_av) {
     const uint32_t row = gid / W, col = gid - row * W;
@@ -82,11 +85,14 @@ __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
   }
   if (gid < n_av + n_gs) {
     const uint32_t i = gid - n_av;
-    const uint32_t AO = A * O;
-    const uint32_t et = i / AO, c = i - et * AO;   // (env, tile), column in the concatenated state
+    const uint32_t et = i / gsw, c = i - et * gsw;   // (env, tile), column in the state row
     const uint32_t e = et / (uint32_t)a.gs_tiles;
-    const uint32_t ag = c / O, f = c - ag * O;
-    a.global_state[i] = synth_raw_feature((a.env_offset + e) * A + ag, (int)f, a);
+    if (a.S > 0) {
+      a.global_state[i] = synth_raw_feature(0x80000000u | (a.env_offset + e), (int)c, a);
+    } else {
+      const uint32_t ag = c / O, f = c - ag * O;
+      a.global_state[i] = synth_raw_feature((a.env_offset + e) * A + ag, (int)f, a);
+    }
     return;
   }
   const uint32_t k = gid - n_av - n_gs;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
 
 }  // namespace
 
-extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int time_limit,
+extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int state_dim, int time_limit,
                                      uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
                                      int32_t* step_count, float* run_return, int32_t* run_length,
                                      float* ep_return, int32_t* ep_length, float* agents_view,
@@ -149,7 +155,8 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
                                      uint8_t* info_terminal, hipStream_t s) {
   MAVA_ARG_CHECK(E >= 0 && A >= 1 && O >= 2 && n_actions >= 1 && time_limit >= 1, 0,
                  "mava_synth_rware_step: bad shape E=%d A=%d O=%d nA=%d", E, A, O, n_actions);
-  MAVA_ARG_CHECK(gs_tiles == 1 || gs_tiles == A, 1, "mava_synth_rware_step: gs_tiles must be 1 or A");
+  MAVA_ARG_CHECK((gs_tiles == 1 || gs_tiles == A) && state_dim >= 0, 1,
+                 "mava_synth_rware_step: gs_tiles must be 1 or A, state_dim >= 0");
   if (E == 0) return MAVA_OK;
   MAVA_ARG_CHECK(step_count && run_return && run_length && ep_return && ep_length && agents_view &&
                      global_state && action_mask && obs_step_count,
@@ -157,14 +164,14 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
   MAVA_ARG_CHECK(is_reset || (reward && done && info_return && info_length && info_terminal), 3,
                  "mava_synth_rware_step: null transition pointer");
   SynthArgs a;
-  a.E = E; a.A = A; a.O = O; a.nA = n_actions; a.gs_tiles = gs_tiles; a.time_limit = time_limit;
+  a.E = E; a.A = A; a.O = O; a.nA = n_actions; a.gs_tiles = gs_tiles; a.S = state_dim; a.time_limit = time_limit;
   a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.t = t; a.env_offset = env_offset;
   a.step_count = step_count; a.run_return = run_return; a.run_length = run_length;
   a.ep_return = ep_return; a.ep_length = ep_length; a.agents_view = agents_view;
   a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;
   a.reward = reward; a.done = done; a.info_return = info_return; a.info_length = info_length;
   a.info_terminal = info_terminal; a.is_reset = is_reset;
-  const long total = (long)E * A * (A + O) + (long)E * gs_tiles * A * O + (long)E * A;
+  const long total = (long)E * A * (A + O) + (long)E * gs_tiles * (state_dim > 0 ? state_dim : A * O) + (long)E * A;
   MAVA_ARG_CHECK(total < (1L << 32), 4, "mava_synth_rware_step: %ld output elements exceed 32-bit indexing", total);
   hipLaunchKernelGGL(synth_rware_kernel, dim3(mava_cdiv(total, 256)), dim3(256), 0, s, a);
   MAVA_LAUNCH_CHECK();

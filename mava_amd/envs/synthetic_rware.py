@@ -40,7 +40,7 @@ class SyntheticRware:
 
     def __init__(self, num_envs: int, num_agents: int, obs_dim: int = 66, num_actions: int = 5, time_limit: int = 500,
                  add_global_state: bool = False, add_agent_id: bool = True, seed: int = 42, env_offset: int = 0,
-                 tile_global_state: bool = False, device: Optional[torch.device] = None):
+                 tile_global_state: bool = False, device: Optional[torch.device] = None, state_dim: int = 0):
         if not add_agent_id:
             raise NotImplementedError("the synthetic generator always prepends the agent one-hot id (add_agent_id=True)")
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
@@ -48,13 +48,15 @@ class SyntheticRware:
         self.add_global_state = add_global_state
         self.seed, self.env_offset = int(seed), int(env_offset)
         self.gs_tiles = self.num_agents if tile_global_state else 1
+        self.synth_state_dim = int(state_dim)  # 0: global_state = concatenated raw views; > 0: own state vector
         self.global_state_shared = not tile_global_state
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     def clone(self, env_offset: int, num_envs: Optional[int] = None) -> "SyntheticRware":
         """Same environment family on a disjoint range of global env ids (one per replica / rank)."""
         return SyntheticRware(num_envs or self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.time_limit,
-                              self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device)
+                              self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device,
+                              self.synth_state_dim)
 
     # ---- specs ----------------------------------------------------------------------------
     @property
@@ -63,7 +65,7 @@ class SyntheticRware:
 
     @property
     def state_dim(self) -> int:
-        return self.num_agents * self.raw_obs_dim
+        return self.synth_state_dim if self.synth_state_dim > 0 else self.num_agents * self.raw_obs_dim
 
     def observation_spec(self) -> ObsSpec:
         A = self.num_agents
@@ -92,7 +94,7 @@ class SyntheticRware:
         off = self.env_offset if env_offset is None else env_offset
         check(
             lib().mava_synth_rware_step(self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.gs_tiles,
-                                        self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, off & 0xFFFFFFFF,
+                                        self.synth_state_dim, self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, off & 0xFFFFFFFF,
                                         int(is_reset), ptr(state.step_count), ptr(state.run_return), ptr(state.run_length),
                                         ptr(state.ep_return), ptr(state.ep_length), ptr(obs["agents_view"]),
                                         ptr(obs["global_state"]), ptr(obs["action_mask"]), ptr(obs["step_count"]),
@@ -147,7 +149,7 @@ def make(config, add_global_state: bool = False, device=None, env_offset: int = 
     kw = dict(num_agents=int(tc.num_agents), obs_dim=int(syn["obs_dim"]), num_actions=int(syn["num_actions"]),
               time_limit=int(config.env.kwargs.get("time_limit", 500)), add_global_state=add_global_state,
               add_agent_id=bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id),
-              seed=int(config.system.seed), device=device)
+              seed=int(config.system.seed), device=device, state_dim=int(syn.get("state_dim", 0) or 0))
     train = SyntheticRware(num_envs=int(config.arch.num_envs), env_offset=env_offset, **kw)
     evale = SyntheticRware(num_envs=int(config.arch.num_eval_episodes), env_offset=env_offset + (1 << 30), **kw)
     return train, evale

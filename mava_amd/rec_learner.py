@@ -1,0 +1,288 @@
+"""Recurrent PPO learner (rec_ippo / rec_mappo) behind Mava's LearnerFn contract.
+
+Reference: mava/systems/ppo/rec_mappo.py:45-434 (get_learner_fn) and :437-576 (learner_setup);
+rec_ippo.py is the same file with a decentralised critic.  Differences from the feed-forward learner
+(mava_amd/learner.py), all visible in the cited lines:
+  * the carry holds `dones` (E, A) and the GRU hidden states of actor and critic (:91-105, RNNLearnerState);
+  * a transition stores the done flag ENTERING the step and the loss re-unrolls the whole sequence from
+    the hidden state at the start of the rollout, hstates[0] (:136-145, :219-222, :252-255);
+  * GAE masks with the NEXT step's stored flag and is seeded with the post-rollout `dones` (:177-199);
+  * minibatches are slices of a permutation over ENVS and keep all T steps (:334-365); only
+    recurrent_chunk_size == rollout_length is meaningful and anything else is rejected.
+
+Kernel chain per network and minibatch (mava_amd/rec_networks.py): dense(pre) -> dense(gi) -> GRU scan ->
+dense(post) -> dense(head) -> sequence loss -> dense(dpost) -> dense(dh) -> GRU BPTT scan -> dense(dxpre)
+-> five X^T Y weight-gradient products; then [all-reduce] and the same fused clip+Adam as the ff systems.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import ops, parallel
+from ._lib import check, lib, ptr, stream_ptr
+from .learner import NUM_CU, _Replica
+from .networks import DiscreteActionHead, MLPTorso
+from .rec_networks import H, RecurrentActor, RecurrentValueNet, RecWorkspace, rows_to_t32, t32_to_rows
+from .types import (AdamState, ExperimentOutput, HiddenStates, Observation, ObservationGlobalState, OptStates, Params,
+                    RNNLearnerState, TimeStep)
+
+
+class _RecReplica(_Replica):
+    def __init__(self, env, T, n_upd, central, device):
+        super().__init__(env, T, n_upd, central, device)
+        E, A = env.num_envs, env.num_agents
+        EA = E * A
+        if EA % 32:
+            raise ValueError(f"num_envs * num_agents = {EA} must be a multiple of 32 for the recurrent kernels")
+        self.dones = torch.zeros((E, A), dtype=torch.uint8, device=device)       # flag entering the next step
+        self.done_in = torch.zeros((T, E, A), dtype=torch.uint8, device=device)  # transition.done = last_done (:136-137)
+        # current hidden states in the kernels' T32 layout, and the rollout-initial copies (hstates[0], row-major)
+        self.h_actor = torch.zeros(EA * H, device=device)
+        self.h_critic = torch.zeros(EA * H, device=device)
+        self.h0_actor = torch.zeros((E, A, H), device=device)
+        self.h0_critic = torch.zeros((E, A, H), device=device)
+
+
+class RecLearner:
+    def __init__(self, env, config, centralised_critic: bool, device: Optional[torch.device] = None):
+        self.config = config
+        self.centralised = centralised_critic
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rank, self.world = parallel.rank_world()
+        s, arch = config.system, config.arch
+        self.E, self.U, self.T = int(arch.num_envs), int(s.update_batch_size), int(s.rollout_length)
+        self.K, self.M = int(s.ppo_epochs), int(s.num_minibatches)
+        chunk = s.get("recurrent_chunk_size", None)
+        if chunk is not None and int(chunk) != self.T:
+            # rec_mappo.py:342-349 reshapes (T,E,..)->(chunk, E*n,..) row-major, which interleaves time and env
+            # unless chunk == T; the default (null -> T, :586-587) is the only meaningful setting.
+            raise ValueError("recurrent_chunk_size must be null or equal to rollout_length")
+        if self.E % self.M:
+            raise ValueError("num_envs must be divisible by num_minibatches (rec_mappo.py:354-357)")
+        self.n_upd = int(s.get("num_updates_per_eval", 1))
+        if env.num_envs != self.E:
+            raise ValueError(f"env.num_envs={env.num_envs} != arch.num_envs={self.E}")
+        if centralised_critic and not getattr(env, "add_global_state", False):
+            raise ValueError("Global state must be provided to the centralised critic.")  # networks.py:315-316
+        self.reps: List[_RecReplica] = []
+        for u in range(self.U):
+            rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
+            self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device))
+        env0 = self.reps[0].env
+        self.A, self.nA = env0.num_agents, env0.action_dim
+        config.system.num_agents = self.A
+        self.Oa = env0.obs_dim
+        if centralised_critic:
+            self.Oc = env0.state_dim
+            self.critic_share = self.A if env0.global_state_shared else 1
+        else:
+            self.Oc, self.critic_share = self.Oa, 1
+        self.Em = self.E // self.M
+        self.Rm = self.Em * self.A
+        if self.Rm % 32:
+            raise ValueError(f"(num_envs / num_minibatches) * num_agents = {self.Rm} must be a multiple of 32")
+
+        net = config.network
+        mk = lambda c: MLPTorso(**{k: v for k, v in c.items() if k != "_target_"})
+        hsd = int(net.get("hidden_state_dim", 128))
+        self.actor_network = RecurrentActor(mk(net.actor_network.pre_torso), mk(net.actor_network.post_torso),
+                                            DiscreteActionHead(self.nA), self.Oa, hsd)
+        self.critic_network = RecurrentValueNet(mk(net.critic_network.pre_torso), mk(net.critic_network.post_torso),
+                                                centralised_critic, self.Oc, hsd)
+        for t in (net.actor_network.pre_torso, net.actor_network.post_torso, net.critic_network.pre_torso,
+                  net.critic_network.post_torso):
+            mk(t).require([128])
+        self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
+        self.P = self.Pa + self.Pc
+
+        d = self.device
+        self.p = torch.zeros(self.P, device=d)
+        self.m = torch.zeros(self.P, device=d)
+        self.v = torch.zeros(self.P, device=d)
+        self.count = torch.zeros(2, dtype=torch.int32, device=d)
+        self.g = torch.zeros(self.P + 4, device=d)
+        self.seg_off = [0, self.Pa, self.P]
+        self.seg_lr = [float(s.actor_lr), float(s.critic_lr)]
+        self.ws_roll = RecWorkspace(self.E * self.A, max(self.nA, 1), d, training=False)
+        self.ws = RecWorkspace(self.T * self.Rm, max(self.nA, 1), d, training=True)
+        n_slab = max(1, min(NUM_CU, (self.T * self.Rm) // 32))
+        self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
+        self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
+        self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
+        self.perm_gen = torch.Generator(device=d)
+        self.t_global = 0
+        self.seed = int(s.seed)
+        self._t_range = torch.arange(self.T, device=d, dtype=torch.int64)[:, None] * self.E
+
+    # ------------------------------------------------------------------------------------ setup
+    def init_params(self, actor_seed: int, critic_seed: int) -> None:
+        self.p[: self.Pa].copy_(self.actor_network.init_flat(actor_seed))
+        self.p[self.Pa :].copy_(self.critic_network.init_flat(critic_seed))
+        self.m.zero_()
+        self.v.zero_()
+        self.count.zero_()
+
+    def reset_envs(self) -> None:
+        for rep in self.reps:
+            rep.env.step_into(rep.state, 0, rep.obs_slot(0), is_reset=True)
+            rep.dones.zero_()      # rec_mappo.py:555-558
+            rep.h_actor.zero_()    # ScannedRNN.initialize_carry: zeros (:497-502)
+            rep.h_critic.zero_()
+        self.t_global = 0
+        self.perm_gen.manual_seed(self.seed)
+
+    # ---------------------------------------------------------------------------- state views
+    def learner_state(self) -> RNNLearnerState:
+        lead = (1, self.U)
+        params = Params(self.actor_network.tree(self.p[: self.Pa], lead), self.critic_network.tree(self.p[self.Pa :], lead))
+        opts = []
+        for i, (net, sl) in enumerate(((self.actor_network, slice(0, self.Pa)), (self.critic_network, slice(self.Pa, self.P)))):
+            opts.append(AdamState(self.count[i].expand(1, self.U), net.tree(self.m[sl], lead), net.tree(self.v[sl], lead)))
+        key = torch.tensor([[[self.seed, self.t_global]] * self.U], dtype=torch.int64)
+        st = lambda f: torch.stack([f(r) for r in self.reps], 0).unsqueeze(0)
+        E, A = self.E, self.A
+        av, mask, sc = st(lambda r: r.agents_view[0]), st(lambda r: r.action_mask[0]).bool(), st(lambda r: r.step_count[0])
+        if self.centralised:
+            gs = st(lambda r: r.global_state[0].expand(-1, A, -1) if r.env.gs_tiles == 1 else r.global_state[0])
+            obs: Any = ObservationGlobalState(av, mask, gs, sc)
+        else:
+            obs = Observation(av, mask, sc)
+        dones = st(lambda r: r.dones).bool()
+        ts = TimeStep(torch.where(dones[..., 0], 2, 1).to(torch.int8), st(lambda r: r.last_reward), 1.0 - dones.float(), obs, {})
+        hst = HiddenStates(st(lambda r: t32_to_rows(r.h_actor, H, E * A).view(E, A, H)),
+                           st(lambda r: t32_to_rows(r.h_critic, H, E * A).view(E, A, H)))
+        env_state = {"step_count": st(lambda r: r.state.step_count), "episode_return": st(lambda r: r.state.ep_return),
+                     "episode_length": st(lambda r: r.state.ep_length)}
+        return RNNLearnerState(params, OptStates(*opts), key, env_state, ts, dones, hst)
+
+    # ------------------------------------------------------------------------------------ update
+    def _critic_x(self, rep, lo, hi):
+        if self.centralised:
+            return rep.global_state[lo:hi]
+        return rep.agents_view[lo:hi]
+
+    def _rollout(self, n: int) -> None:
+        """rec_mappo.py:91-153: T acting steps; hidden states advance in place (T32), last_done is recorded."""
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        E, A = self.E, self.A
+        EA = E * A
+        ws = self.ws_roll
+        for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
+            rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
+            rep.h0_critic.view(EA, H).copy_(t32_to_rows(rep.h_critic, H, EA))
+        for t in range(self.T):
+            step = self.t_global + t
+            for u, rep in enumerate(self.reps):
+                rep.done_in[t].copy_(rep.dones)
+                d1 = rep.done_in[t : t + 1]
+                self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E, A,
+                                                    training=False)
+                rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
+                check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
+                                                step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
+                                                ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
+                # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
+                self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1, rep.h_critic, True,
+                                                     None, 1, EA, E, A, training=False, y_out=rep.value[t])
+                rep.h_critic, ws.hs = ws.hs, rep.h_critic
+                rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
+                                  rep.info_length[n, t], rep.info_terminal[n, t])
+                rep.dones.copy_(rep.done[t])
+                if t == self.T - 1:
+                    rep.last_reward.copy_(rep.reward[t])
+        self.t_global += self.T
+
+    def _bootstrap_and_gae(self) -> None:
+        """rec_mappo.py:155-199: last_val from one more critic step (hidden state NOT advanced), then GAE with
+        next_done masking seeded by the post-rollout dones."""
+        s = self.config.system
+        pc = self.p[self.Pa :]
+        E, A, T = self.E, self.A, self.T
+        EA = E * A
+        for rep in self.reps:
+            self.critic_network.forward_sequence(pc, self.ws_roll, self._critic_x(rep, T, T + 1), self.critic_share,
+                                                 rep.dones.view(1, E, A), rep.h_critic, True, None, 1, EA, E, A, training=False,
+                                                 y_out=rep.last_val)
+            ops.gae(rep.reward.view(T, EA), rep.value.view(T, EA), rep.done_in.view(T, EA), rep.last_val.view(EA),
+                    float(s.gamma), float(s.gae_lambda), last_done=rep.dones.view(EA), out=(rep.adv.view(T, EA), rep.tgt.view(T, EA)))
+
+    def _minibatch(self, n: int, k: int, mb: int, perm: torch.Tensor) -> None:
+        s = self.config.system
+        T, E, A, Em, Rm = self.T, self.E, self.A, self.Em, self.Rm
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        idx = perm[mb * Em : (mb + 1) * Em].contiguous()
+        flat_rows = (self._t_range + idx[None, :].long()).reshape(-1).to(torch.int32)  # (t*E + env) rows of the minibatch
+        ws, L, st = self.ws, lib(), stream_ptr()
+        nblk = ws.loss_partials.shape[0]
+        for u, rep in enumerate(self.reps):
+            acc = u > 0
+            # ---- actor (rec_mappo.py:210-242)
+            self.actor_network.forward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, rep.h0_actor, False, idx, T, Rm, E, A,
+                                                training=True)
+            ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
+            check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
+                                            ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps),
+                                            float(s.ent_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st), "mava_seq_actor_loss_f32")
+            ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
+            self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, self.slabs,
+                                                 self.g[: self.Pa], accumulate=acc)
+            # ---- critic (rec_mappo.py:244-266)
+            cx = self._critic_x(rep, 0, T)
+            self.critic_network.forward_sequence(pc, ws, cx, self.critic_share, rep.done_in, rep.h0_critic, False, idx, T, Rm, E, A,
+                                                 training=True)
+            check(L.mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt), float(s.clip_eps),
+                                             float(s.vf_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st), "mava_seq_critic_loss_f32")
+            ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
+            self.critic_network.backward_sequence(pc, ws, cx, self.critic_share, rep.done_in, idx, T, Rm, E, A, self.slabs,
+                                                  self.g[self.Pa : self.P], accumulate=acc)
+        parallel.allreduce_sum_(self.g)
+        ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
+                      grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
+                      decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
+                      num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
+                      ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
+
+    def update(self, n: int, permutations: Optional[List[torch.Tensor]] = None) -> None:
+        self._rollout(n)
+        self._bootstrap_and_gae()
+        for k in range(self.K):
+            perm = (permutations[k] if permutations is not None
+                    else torch.randperm(self.E, generator=self.perm_gen, device=self.device).to(torch.int32))
+            for mb in range(self.M):
+                self._minibatch(n, k, mb, perm)
+        for rep in self.reps:
+            rep.agents_view[0].copy_(rep.agents_view[self.T])
+            rep.global_state[0].copy_(rep.global_state[self.T])
+            rep.action_mask[0].copy_(rep.action_mask[self.T])
+            rep.step_count[0].copy_(rep.step_count[self.T])
+
+    def learn(self, learner_state: RNNLearnerState) -> ExperimentOutput:
+        for n in range(self.n_upd):
+            self.update(n)
+        U = self.U
+        episode_metrics = {
+            "episode_return": torch.stack([r.info_return for r in self.reps], 1).unsqueeze(0),
+            "episode_length": torch.stack([r.info_length for r in self.reps], 1).unsqueeze(0),
+            "is_terminal_step": torch.stack([r.info_terminal for r in self.reps], 1).unsqueeze(0).bool(),
+        }
+        tm = self.train_metrics.unsqueeze(1).expand(self.n_upd, U, self.K, self.M, 4).unsqueeze(0)
+        train_metrics = {"total_loss": tm[..., 0], "value_loss": tm[..., 1], "actor_loss": tm[..., 2], "entropy": tm[..., 3]}
+        return ExperimentOutput(self.learner_state(), episode_metrics, train_metrics)
+
+
+def learner_setup(env, keys, config, centralised_critic: bool, device=None):
+    """Counterpart of learner_setup (rec_mappo.py:437-576): (learn, actor_network, init RNNLearnerState)."""
+    key, actor_key, critic_key = (int(k) for k in keys)
+    learner = RecLearner(env, config, centralised_critic, device)
+    learner.seed = key
+    learner.init_params(actor_key, critic_key)
+    parallel.broadcast_(learner.p, src=0)
+    learner.reset_envs()
+
+    def learn(learner_state: RNNLearnerState) -> ExperimentOutput:
+        return learner.learn(learner_state)
+
+    learn.learner = learner  # type: ignore[attr-defined]
+    return learn, learner.actor_network, learner.learner_state()

@@ -101,25 +101,35 @@ class _RecurrentNet:
 
     # ------------------------------------------------------------------------------------- kernels
     def forward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, h0, h0_t32, idx, T, Rm, E, A,
-                         training: bool) -> torch.Tensor:
+                         training: bool, y_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Runs the network over a time-major sequence batch; returns T32 outputs (ws.y).  x_ext is the external
         row-major (T, E, A/x_share.., din) tensor, done_ext (T, E, A) u8 the flags entering each step."""
         rows = T * Rm
         L = lib()
         s = stream_ptr()
         W = lambda n: ptr(self.seg(flat, n))
-        check(L.mava_rec_dense_f32(ptr(x_ext), 1, ptr(idx), Rm, E, A, x_share, W("Wpre"), H, W("bpre"), None, ptr(ws.xpre),
-                                   self.din, H, rows, 1, s), "rec_dense(pre)")
-        check(L.mava_rec_dense_f32(ptr(ws.xpre), 0, None, 0, 0, 0, 1, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H, G3, rows, 0, s),
+        # pre-torso: inputs wider than 384 are consumed in column blocks (accumulating products; the weight
+        # slice of one block stays register-resident), the ReLU rides on the last block
+        din, Wpre = self.din, self.seg(flat, "Wpre")
+        k0 = 0
+        while k0 < din:
+            kc = min(384, din - k0)
+            last = k0 + kc >= din
+            check(L.mava_rec_dense_f32(x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din, int(k0 > 0),
+                                       Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre),
+                                       kc, H, rows, int(last), s), "rec_dense(pre)")
+            k0 += kc
+        check(L.mava_rec_dense_f32(ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H, G3, rows, 0, s),
               "rec_dense(gi)")
         check(L.mava_gru_scan_fwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"), ptr(ws.gi),
                                       ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s),
               "gru_scan_fwd")
-        check(L.mava_rec_dense_f32(ptr(ws.hs), 0, None, 0, 0, 0, 1, W("Wpost"), H, W("bpost"), None, ptr(ws.post), H, H, rows, 1, s),
-              "rec_dense(post)")
-        check(L.mava_rec_dense_f32(ptr(ws.post), 0, None, 0, 0, 0, 1, W("Whead"), self.n_out, W("bhead"), None, ptr(ws.y), H,
+        check(L.mava_rec_dense_f32(ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None, ptr(ws.post), H, H, rows,
+                                   1, s), "rec_dense(post)")
+        y = ws.y if y_out is None else y_out
+        check(L.mava_rec_dense_f32(ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"), None, ptr(y), H,
                                    self.n_out, rows, 0, s), "rec_dense(head)")
-        return ws.y
+        return y
 
     def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
                           accumulate: bool) -> None:
@@ -133,32 +143,34 @@ class _RecurrentNet:
         WpostT = self.seg(flat, "Wpost").t().contiguous()
         WiT = self.seg(flat, "Wi").t().contiguous()
         d = lambda k, N, x, w, ldw, gate, y: check(
-            L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, ptr(w), ldw, None, ptr(gate), ptr(y), k, N, rows, 0, s), "rec_dense(bwd)")
+            L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), k, N, rows, 0, s),
+            "rec_dense(bwd)")
         d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
         d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
         check(L.mava_gru_scan_bwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved), ptr(ws.hprev),
                                       ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s), "gru_scan_bwd")
         d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
 
-        def xty(x, x_rowmajor, K, N, y, wname, bname, xs=1, bias_slice=None):
-            n_slab = slabs.shape[0]
-            check(L.mava_rec_xty_f32(ptr(x), x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, ptr(y), K, N, rows, 1,
-                                     ptr(slabs), slabs.shape[1], n_slab, s), f"rec_xty({wname})")
-            ow, sw = self.off[wname]
-            ops.slab_reduce(slabs, K * N, grad_out[ow : ow + K * N], accumulate=accumulate)
-            if bname is not None:
-                ob, sb = self.off[bname]
-                nb = math.prod(sb)
-                src = slabs[:, K * N :] if bias_slice is None else slabs[:, K * N + bias_slice :]
-                # strided view of the slab tail: reduce through the generic reducer on a contiguous copy of the tail
-                tail = src[:, :nb].contiguous()
-                ops.slab_reduce(tail, nb, grad_out[ob : ob + nb], accumulate=accumulate)
+        def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
+            """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
+            check(L.mava_rec_xty_f32(x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), K, N, rows, 1,
+                                     ptr(slabs), slabs.shape[1], slabs.shape[0], s), "rec_xty")
+            ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
+            if b_off is not None:
+                tail = slabs[:, K * N + bias_slice : K * N + bias_slice + nb].contiguous()
+                ops.slab_reduce(tail, nb, grad_out[b_off : b_off + nb], accumulate=accumulate)
 
-        xty(ws.post, 0, H, n_out, ws.dy, "Whead", "bhead")
-        xty(ws.hs, 0, H, H, ws.dpost, "Wpost", "bpost")
-        xty(ws.xpre, 0, H, G3, ws.dgi, "Wi", "bi")
-        xty(ws.hprev, 0, H, G3, ws.dgh, "Wh", "bhn", bias_slice=2 * H)  # db_hn = colsum of the n-part of dgh
-        xty(x_ext, 1, self.din, H, ws.dxpre, "Wpre", "bpre", xs=x_share)
+        o = lambda n: self.off[n][0]
+        xty(ptr(ws.post), 0, H, H, n_out, ws.dy, o("Whead"), o("bhead"), n_out)
+        xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
+        xty(ptr(ws.xpre), 0, H, H, G3, ws.dgi, o("Wi"), o("bi"), G3)
+        xty(ptr(ws.hprev), 0, H, H, G3, ws.dgh, o("Wh"), o("bhn"), H, bias_slice=2 * H)  # db_hn: n-part of colsum(dgh)
+        k0 = 0
+        while k0 < self.din:  # column blocks of wide inputs (each block's rows of W_pre are contiguous)
+            kc = min(384, self.din - k0)
+            xty(x_ext.data_ptr() + 4 * k0, 1, self.din, kc, H, ws.dxpre, o("Wpre") + k0 * H, o("bpre") if k0 == 0 else None, H,
+                xs=x_share)
+            k0 += kc
 
 
 class RecurrentActor(_RecurrentNet):

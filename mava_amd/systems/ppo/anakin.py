@@ -18,7 +18,7 @@ from ...learner import get_final_step_metrics
 
 
 def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable, add_global_state: bool,
-                   log: Optional[Callable[[Dict[str, Any]], None]] = None) -> float:
+                   log: Optional[Callable[[Dict[str, Any]], None]] = None, recurrent: bool = False) -> float:
     config = copy.deepcopy(_config)
     import torch.distributed as dist
 
@@ -41,7 +41,10 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
 
     from ...evaluator import get_eval_fn, make_ff_eval_act_fn
 
-    evaluator = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, config), config, absolute_metric=False)
+    # The evaluator runs the feed-forward act function; the recurrent act function (evaluator.py:189-207) is
+    # not built yet, so recurrent systems skip evaluation and report training metrics only.
+    evaluator = None if recurrent else get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, config), config,
+                                                   absolute_metric=False)
 
     def emit(rec: Dict[str, Any]) -> None:
         if rank == 0:
@@ -63,10 +66,13 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
         for k, v in out.train_metrics.items():
             rec[k] = float(v.float().mean())  # TRAIN metrics are mean-reduced (mava/utils/logger.py:72-74)
         # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:513 vs :535)
-        trained_params = learner_state.params.actor_params
-        eval_metrics = evaluator(trained_params, key_e + eval_step)
-        eval_return = float(eval_metrics["episode_return"].float().mean())
-        rec["eval_episode_return"] = eval_return
+        if evaluator is not None:
+            trained_params = learner_state.params.actor_params
+            eval_metrics = evaluator(trained_params, key_e + eval_step)
+            eval_return = float(eval_metrics["episode_return"].float().mean())
+            rec["eval_episode_return"] = eval_return
+        else:
+            eval_return = rec.get("episode_return", 0.0)
         emit(rec)
         learner_state = out.learner_state
     return eval_return

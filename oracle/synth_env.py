@@ -19,9 +19,10 @@ from .philox import ENV_STREAM, philox4x32_10, u01_open
 
 class SynthRware:
     def __init__(self, E: int, A: int, O: int = 66, n_actions: int = 5, time_limit: int = 500, seed: int = 42,
-                 env_offset: int = 0, gs_tiles: int = 1):
+                 env_offset: int = 0, gs_tiles: int = 1, state_dim: int = 0):
         self.E, self.A, self.O, self.nA = E, A, O, n_actions
         self.time_limit, self.seed, self.env_offset, self.gs_tiles = time_limit, seed, env_offset, gs_tiles
+        self.state_dim = state_dim
         self.step_count = np.zeros((E, A), np.int32)
         self.run_return = np.zeros(E, np.float32)
         self.run_length = np.zeros(E, np.int32)
@@ -46,7 +47,23 @@ class SynthRware:
                     byte = (w[q >> 2] >> np.uint32(8 * (q & 3))) & np.uint32(0xFF)
                     av[:, :, A + f] = (byte < 51).astype(np.float32)
         raw = av[:, :, A:]
-        gs = raw.reshape(E, 1, A * O).repeat(self.gs_tiles, 1)
+        if self.state_dim > 0:  # independent state vector per env: entity id = 0x80000000 | env
+            S = self.state_dim
+            sent = (np.uint32(0x80000000) | env_id).astype(np.uint32)
+            st = np.zeros((E, S), np.float32)
+            cs = philox4x32_10(sent, t, 0xFFFF, ENV_STREAM, slo, shi)
+            st[:, 0] = (cs[0] % np.uint32(10)).astype(np.float32)
+            if S > 1:
+                st[:, 1] = (cs[1] % np.uint32(10)).astype(np.float32)
+            for c in range((S - 2 + 15) // 16):
+                w = philox4x32_10(sent, t, c, ENV_STREAM, slo, shi)
+                for q in range(16):
+                    f = 2 + 16 * c + q
+                    if f < S:
+                        st[:, f] = (((w[q >> 2] >> np.uint32(8 * (q & 3))) & np.uint32(0xFF)) < 51).astype(np.float32)
+            gs = st.reshape(E, 1, S).repeat(self.gs_tiles, 1)
+        else:
+            gs = raw.reshape(E, 1, A * O).repeat(self.gs_tiles, 1)
         mask = np.ones((E, A, self.nA), bool)
         if self.nA > 1:
             mask[:, :, 1] = ~((cm[2] & np.uint32(0xFF)) < 51)

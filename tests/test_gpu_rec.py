@@ -39,7 +39,7 @@ def test_rec_dense_t32(dev, K, N, relu, gated):
     g = rng.standard_normal((rows, N)).astype(np.float32)
     y = torch.zeros(rows * N, device=dev)
     xt, wt, bt, gt = _t(_to_t32(x), dev), _t(w, dev), _t(b, dev), _t(_to_t32(g), dev)
-    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), K, N,
+    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), K, N,
                                    rows, int(relu), stream_ptr()), "dense")
     torch.cuda.synchronize()
     want = x.astype(np.float64) @ w.astype(np.float64) + b
@@ -66,7 +66,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     # NB: every device tensor handed to the C ABI is kept alive in a named variable (a temporary would be
     # freed - and its block recycled by the caching allocator - before the asynchronous kernel reads it)
     obs_d, idx_d, w_d, b_d = _t(obs, dev), _t(idx, dev), _t(w, dev), _t(b, dev)
-    check(lib().mava_rec_dense_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, ptr(w_d), N, ptr(b_d), None,
+    check(lib().mava_rec_dense_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, 0, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), K, N, rows, 1, stream_ptr()), "dense gather")
     xg = obs[:, idx].reshape(rows, K).astype(np.float64)  # time-major, env-major inside a step
     want = np.maximum(xg @ w.astype(np.float64) + b, 0)
@@ -75,7 +75,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     # shared input rows (global state stored once per env)
     gs = rng.standard_normal((T, E, K)).astype(np.float32)
     gs_d = _t(gs, dev)
-    check(lib().mava_rec_dense_f32(ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, ptr(w_d), N, ptr(b_d), None,
+    check(lib().mava_rec_dense_f32(ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, K, 0, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), K, N, rows, 0, stream_ptr()), "dense gather shared")
     want2 = np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64) @ w.astype(np.float64) + b
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want2, 1e-5, "dense gather shared")
@@ -83,7 +83,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     dy = rng.standard_normal((rows, N)).astype(np.float32)
     dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, ptr(dy_d), K, N, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), K, N, rows, 1,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -94,7 +94,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev):
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
     x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, ptr(dy2_d), 128, 384, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 128, 384, rows, 1,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
@@ -212,3 +212,62 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
     tot, vl, g = ro.rec_critic_loss_grad(fc, din, go(obs), go(done), go(h0[None])[0], go(old_v), go(tgt), 0.2, 0.5)
     assert_close(ws.loss_partials.sum(0).cpu().numpy()[:1], np.array([vl]), 1e-5, "value loss", scale=1.0)
     assert_close(gc.cpu().numpy(), g, 1e-4, "recurrent critic gradient")
+
+
+@pytest.mark.parametrize("system,U", [("rec_mappo", 1), ("rec_ippo", 2)])
+def test_rec_learner_update_matches_oracle(dev, system, U):
+    """End to end: the HIP recurrent learner against the whole-update oracle on identical inputs."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_ippo, rec_mappo
+    from oracle import ppo_oracle as po
+    from oracle.rec_loop import OracleRecLearner
+
+    E, A, O, nA, T, K, M = 16, 4, 10, 5, 6, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}"])
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": nA}
+    cfg.env.kwargs.time_limit = 4  # forces resets inside the rollout (hidden-state resets, GAE masking)
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    central = system == "rec_mappo"
+    mod = rec_mappo if central else rec_ippo
+    env, _ = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    assert state.hstates.policy_hidden_state.shape == (1, U, E, A, 128) and state.dones.shape == (1, U, E, A)
+    k = state.params.actor_params["params"]["ScannedRNN_0"]["GRUCell_0"]["hz"]["kernel"]
+    assert k.shape == (1, U, 128, 128)
+
+    rng = np.random.default_rng(1)
+    Oc = A * O if central else A + O
+    fa = ro.init_rec(rng, A + O, nA, 1.0).astype(np.float32)
+    fc = ro.init_rec(rng, Oc, 1, 1.0).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleRecLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=U, centralised=central, seed=42, actor_lr=1e-3, critic_lr=2e-3,
+                           time_limit=4)
+    ora.set_params(fa, fc)
+    for n in range(2):
+        perms = [rng.permutation(E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[u]
+            assert np.array_equal(rep.action.cpu().numpy(), tr["action"]), "sampled actions differ"
+            assert np.array_equal(rep.done_in.cpu().numpy().astype(bool), tr["done_in"])
+            assert tr["done_in"].any(), "the test must exercise hidden-state resets"
+            assert_close(rep.value.cpu().numpy(), tr["value"], 1e-5, "values")
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-5, "log_probs")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], 1e-5, "advantages")
+            assert_close(rep.tgt.cpu().numpy(), tr["tgt"], 1e-5, "targets")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
+        assert_close(L.p[L.Pa :].cpu().numpy() - fc, ora.pc - fc, 2e-3, "critic update")
+        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+    out = learn(L.learner_state())
+    torch.cuda.synchronize()
+    assert out.train_metrics["total_loss"].shape == (1, 2, U, K, M) and torch.isfinite(out.train_metrics["total_loss"]).all()

@@ -67,7 +67,8 @@ def main() -> None:
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (arch.num_envs * update_batch_size)")
     ap.add_argument("--update-batch-size", type=int, default=1)
     ap.add_argument("--scenario", default="tiny-4ag")
-    ap.add_argument("--system", default="ff_mappo", choices=["ff_mappo", "ff_ippo"])
+    ap.add_argument("--system", default="ff_mappo", choices=["ff_mappo", "ff_ippo", "rec_mappo", "rec_ippo"])
+    ap.add_argument("--env", default="rware", choices=["rware", "smax"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -91,16 +92,16 @@ def main() -> None:
 
     from mava_amd import envs
     from mava_amd.config import compose
-    from mava_amd.systems.ppo import ff_ippo, ff_mappo
+    from mava_amd.systems.ppo import ff_ippo, ff_mappo, rec_ippo, rec_mappo
 
     U = args.update_batch_size
     E = args.envs // U
-    cfg = compose(f"default_{args.system}", [f"env/scenario={args.scenario}", f"arch.num_envs={E}",
+    cfg = compose(f"default_{args.system}", [f"env={args.env}", f"env/scenario={args.scenario}", f"arch.num_envs={E}",
                                               f"system.update_batch_size={U}"])
     cfg.system.num_updates_per_eval = 1
     cfg.system.num_updates = max(args.steps + args.warmup, 1)
-    central = args.system == "ff_mappo"
-    mod = ff_mappo if central else ff_ippo
+    central = args.system.endswith("mappo")
+    mod = {"ff_mappo": ff_mappo, "ff_ippo": ff_ippo, "rec_mappo": rec_mappo, "rec_ippo": rec_ippo}[args.system]
     env, _ = envs.make(cfg, add_global_state=central, device=dev)
     learn, actor_network, state = mod.learner_setup(env, (42, 43, 44), cfg, device=dev)
     L = learn.learner
@@ -119,7 +120,7 @@ def main() -> None:
         L.update(0)
         torch.cuda.synchronize()
         log(f"warmup update {i} done")
-    if not args.no_kernel_timers:
+    if not args.no_kernel_timers and hasattr(L, "_timed"):
         L.timers = {}
     barrier()
     t0 = time.perf_counter()
@@ -139,7 +140,8 @@ def main() -> None:
     log(f"timed region: {args.steps} updates in {elapsed:.3f} s -> {value:,.0f} env-steps/s")
 
     out = {
-        "metric": "env-steps/sec (whole node), ff_mappo RWARE tiny-4ag",
+        "metric": ("env-steps/sec (whole node), ff_mappo RWARE tiny-4ag" if args.system == "ff_mappo" and args.env == "rware"
+                   else f"env-steps/sec (whole node), {args.system} {args.env} {args.scenario}"),
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -151,7 +153,7 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.system} RWARE {args.scenario}-shaped synthetic obs, {E * U} envs/GPU "
+        "config": {"workload": f"{args.system} {args.env.upper()} {args.scenario}-shaped synthetic obs, {E * U} envs/GPU "
                                f"(update_batch_size={U} x num_envs={E}), rollout_length={T}, ppo_epochs={K}, "
                                f"num_minibatches={M}, agents={A}, obs={L.Oa}/{L.Oc}, actions={L.nA}, "
                                f"one step = one PPO update = {T * U * E} env-steps per GPU",
@@ -169,7 +171,7 @@ def main() -> None:
     default_shape = (args.envs == 4096 and args.update_batch_size == 1 and args.scenario == "tiny-4ag"
                      and args.system == "ff_mappo")
 
-    if rank == 0 and L.timers:
+    if rank == 0 and getattr(L, "timers", None):
         timers = {k: _ev_ms(v) for k, v in L.timers.items()}
         avg = {k: sum(v) / len(v) for k, v in timers.items() if v}
         rows = L.Rb * A  # agent rows per minibatch launch
@@ -202,7 +204,7 @@ def main() -> None:
         per_update = {k: sum(v) / args.steps for k, v in timers.items()}
         out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in per_update.items()}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("ff"):
         from oracle import cpu_loop
 
         cores = usable_cores()

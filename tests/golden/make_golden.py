@@ -85,7 +85,33 @@ def rng_case(name):
              ep_length=np.stack([s[3]["episode_length"] for s in steps]))
 
 
+def rec_case(name, T, R, din, nA, seed):
+    from oracle import rec_oracle as ro
+
+    rng = np.random.default_rng(seed)
+    fa = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
+    fc = ro.init_rec(rng, din, 1, 1.0).astype(np.float32)
+    obs = rng.standard_normal((T, R, din)).astype(np.float32)
+    done = rng.random((T, R)) < 0.2
+    h0 = (rng.standard_normal((R, 128)) * 0.5).astype(np.float32)
+    mask = rng.random((T, R, nA)) > 0.25
+    action = rng.integers(0, nA, (T, R)).astype(np.int32)
+    np.put_along_axis(mask, action[..., None].astype(np.int64), True, -1)
+    y, hs, hl = ro.rec_forward(fa, din, nA, obs, done, h0)
+    old_lp = (-1.2 + rng.standard_normal((T, R)) * 0.3).astype(np.float32)
+    adv = rng.standard_normal((T, R)).astype(np.float32)
+    v, _, _ = ro.rec_forward(fc, din, 1, obs, done, h0)
+    old_v = (v[..., 0] + rng.standard_normal((T, R)) * 0.2).astype(np.float32)
+    tgt = (v[..., 0] + rng.standard_normal((T, R))).astype(np.float32)
+    ta, la, ent, ga = ro.rec_actor_loss_grad(fa, din, nA, obs, done, h0, mask, action, old_lp, adv, 0.2, 0.01)
+    tc, vl, gc = ro.rec_critic_loss_grad(fc, din, obs, done, h0, old_v, tgt, 0.2, 0.5)
+    np.savez(os.path.join(OUT, name), actor_params=fa, critic_params=fc, obs=obs, done=done, h0=h0, mask=mask, action=action,
+             old_log_prob=old_lp, adv=adv, old_value=old_v, targets=tgt, logits=y, h_last=hl, actor_loss=la, entropy=ent,
+             actor_grad=ga, value_loss=vl, critic_grad=gc, din=din, nA=nA)
+
+
 if __name__ == "__main__":
+    rec_case("rec_small.npz", 5, 32, 12, 5, 6)
     gae_case("gae_small.npz", 8, 4, 2, 1)
     gae_case("gae_cfg1.npz", 128, 16, 2, 2)
     loss_case("loss_small.npz", 48, 10, 2, 5, 3)

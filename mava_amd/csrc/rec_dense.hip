@@ -42,7 +42,9 @@ __device__ __forceinline__ long gather_row(const DenseTask& tk, int q) {
 }
 
 // NB = K padded to 16-input batches; NTW = 32-feature output tiles per wave (tiles w, w+4, w+8)
-template <int NB, int NTW>
+// RM: row-major gathered input (else T32).  FULLK (T32 only): K == 16*NB, so operand addresses are
+// compile-time offsets (a per-load clamp makes the compiler hoist one 64-bit address per load out of the tile loop).
+template <int NB, int NTW, bool RM, bool FULLK>
 __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // row-major input only: XS[32][ldx]
   const int tid = threadIdx.x;
@@ -64,70 +66,14 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
         wreg[tw][b][s] = (k < K && col < N) ? tk.w[(long)k * tk.ldw + col] : 0.0f;
       }
   }
-  if (tk.x_rowmajor) {
+  if (RM) {
     for (int i = tid; i < 32 * ldx; i += 256) lds[i] = 0.0f;
     __syncthreads();
   }
 
   const int ntiles = tk.rows / 32;
-  for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
-    const float* xb;  // B operand base: x[row j][k + h] at xb[k * kstride]
-    int kstride;
-    if (tk.x_rowmajor) {
-      __syncthreads();  // previous tile's readers done
-      // stage 32 gathered rows: 8 threads per row, dword pieces (immediate offsets)
-      const int srow = tid >> 3, l8 = tid & 7;
-      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld + l8;
-      float* xs = lds + srow * ldx + l8;
-      const int nfull = K >> 3;
-#pragma unroll
-      for (int i = 0; i < 2 * NB; ++i) {
-        if (i < nfull) xs[8 * i] = xrow[8 * i];
-        else if (i == nfull && l8 + 8 * i < K) xs[8 * i] = xrow[8 * i];
-      }
-      __syncthreads();
-      xb = lds + j * ldx + h;
-      kstride = 1;
-    } else {
-      xb = tk.x + ((long)it * K + h) * 32 + j;  // T32: elem(row j, k) at (it*K + k)*32 + j
-      kstride = 32;
-    }
-
-    f32x16 acc[NTW];
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw) {
-      const int fb = 32 * (w + 4 * tw) + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = fb + (r & 3) + 8 * (r >> 2);
-        float a0 = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
-        if (tk.accumulate && f < N) a0 += tk.y[((long)it * N + f) * 32 + j];
-        acc[tw][r] = a0;
-      }
-    }
-    // B operands one batch ahead (LDS or L2/HBM latency behind the MFMAs of the previous batch)
-    float xo[2][8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) xo[0][s] = (2 * s + h < K) ? xb[(2 * s) * kstride] : 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b + 1 < NB) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int k = 16 * (b + 1) + 2 * s;
-          xo[(b + 1) & 1][s] = (k + h < K) ? xb[(long)k * kstride] : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
-        if (w + 4 * tw < ntile_n) {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) acc[tw] = MFMA32(wreg[tw][b][s], xo[b & 1][s], acc[tw]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // epilogue: activation, optional relu-mask gate, coalesced T32 store
+  auto epilogue = [&](int it, f32x16 (&acc)[NTW]) {
+    // activation, optional relu-mask gate, coalesced T32 store
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
@@ -142,6 +88,113 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
           tk.y[o] = v;
         }
       }
+    }
+  };
+  auto init_acc = [&](int it, f32x16 (&acc)[NTW]) {
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int fb = 32 * (w + 4 * tw) + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fb + (r & 3) + 8 * (r >> 2);
+        float a0 = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
+        if (tk.accumulate && f < N) a0 += tk.y[((long)it * N + f) * 32 + j];
+        acc[tw][r] = a0;
+      }
+    }
+  };
+
+  if (RM) {
+    // ---- row-major source: gather 32 rows into LDS, B operands one batch ahead
+    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+      __syncthreads();  // previous tile's readers done
+      const int srow = tid >> 3, l8 = tid & 7;
+      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld + l8;
+      float* xs = lds + srow * ldx + l8;
+      const int nfull = K >> 3;
+#pragma unroll
+      for (int i = 0; i < 2 * NB; ++i) {
+        if (i < nfull) xs[8 * i] = xrow[8 * i];
+        else if (i == nfull && l8 + 8 * i < K) xs[8 * i] = xrow[8 * i];
+      }
+      __syncthreads();
+      const float* xb = lds + j * ldx + h;  // x[row j][k + h], zero padded
+      f32x16 acc[NTW];
+      init_acc(it, acc);
+      float xo[2][8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xo[0][s] = xb[2 * s];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) xo[(b + 1) & 1][s] = xb[16 * (b + 1) + 2 * s];
+        }
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw) {
+          if (w + 4 * tw < ntile_n) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[tw] = MFMA32(wreg[tw][b][s], xo[b & 1][s], acc[tw]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      epilogue(it, acc);
+    }
+  } else {
+    // ---- T32 source: B operands stream straight from memory through a ring of RDX batches that runs
+    // ACROSS row tiles (prefetch distance RDX-1 batches, also over the tile boundary), so neither the HBM
+    // latency of a batch nor the start-up latency of a tile is exposed.  Inputs past K are clamped to a
+    // valid feature (their weights are zero).
+    // ring depth: deep when the weight slice is small, shallow when it already fills most of the register file
+    constexpr bool BIGW = (NB * NTW * 8 > 128);
+    constexpr int RDX = BIGW ? ((NB % 4 == 0) ? 4 : ((NB % 3 == 0) ? 3 : 2))
+                             : ((NB % 8 == 0) ? 8 : ((NB % 6 == 0) ? 6 : ((NB % 4 == 0) ? 4 : 2)));
+    constexpr int PD = RDX - 1;
+    static_assert(NB % RDX == 0, "ring depth must divide the batch count");
+    auto tile_ptr = [&](int it) { return tk.x + ((long)it * K + (FULLK ? h : 0)) * 32 + j; };
+    auto load_batch = [&](const float* xp, int bq, float (&dst)[8]) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (FULLK) {
+          dst[s] = xp[(16 * bq + 2 * s) * 32];  // elem(row j, k + h): h folded into the tile pointer
+        } else {
+          int k = 16 * bq + 2 * s + h;
+          k = k < K ? k : (K - 1);
+          dst[s] = xp[(long)k * 32];
+        }
+      }
+    };
+    float xo[RDX][8];
+    int it = blockIdx.x;
+    const float* xt_cur = tile_ptr(it < ntiles ? it : 0);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) load_batch(xt_cur, d % NB, xo[d]);  // PD <= NB - 1 always (RDX divides NB)
+    for (; it < ntiles; it += gridDim.x) {
+      const int itn = it + gridDim.x;
+      const float* xt_next = (itn < ntiles) ? tile_ptr(itn) : xt_cur;
+      f32x16 acc[NTW];
+      init_acc(it, acc);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int bq = b + PD;
+          if (bq < NB) load_batch(xt_cur, bq, xo[bq % RDX]);
+          else load_batch(xt_next, bq - NB, xo[bq % RDX]);
+        }
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw) {
+          if (w + 4 * tw < ntile_n) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[tw] = MFMA32(wreg[tw][b][s], xo[b % RDX][s], acc[tw]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      epilogue(it, acc);
+      xt_cur = xt_next;
     }
   }
 }
@@ -184,30 +237,66 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
   for (int i = tid; i < (32 * KT + npad) * LD; i += 256) lds[i] = 0.0f;
   __syncthreads();
 
-  const int ntiles = tk.rows / 32;
-  for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
-    __syncthreads();
-    // ---- stage y^T (T32 source is already feature-major: contiguous 32-row runs)
-    for (int i = tid; i < N * 32; i += 256) {
-      const int f = i >> 5, r = i & 31;
-      YT[f * LD + r] = tk.y[((long)it * N) * 32 + i];
+  // Tiles are register-prefetched one row tile ahead with 16-byte loads (a T32 tile is one contiguous
+  // run of K*32 / N*32 floats) and committed to LDS after the MFMAs of the current tile.
+  constexpr int NT_ALL = 4 * NTW;  // n tiles handled by the block
+  float4 xq[KT], yq[NT_ALL];
+  const int nx4 = K * 8, ny4 = N * 8;  // float4 per tile
+  auto issue = [&](int it) {
+    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * N) * 32);
+#pragma unroll
+    for (int i = 0; i < NT_ALL; ++i) {
+      const int q = tid + 256 * i;
+      yq[i] = ysrc[q < ny4 ? q : (ny4 - 1)];
     }
-    if (tk.x_rowmajor) {
-      const int srow = tid >> 3, l8 = tid & 7;
-      const float* xrow = tk.x + ((long)0) * 0;
-      {
-        DenseTask g;
-        g.Rm = tk.Rm; g.E = tk.E; g.A = tk.A; g.xshare = tk.xshare; g.idx = tk.idx;
-        xrow = tk.x + gather_row(g, it * 32 + srow) * tk.x_ld;
+    if (!tk.x_rowmajor) {
+      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * K) * 32);
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        const int q = tid + 256 * i;
+        xq[i] = xsrc[q < nx4 ? q : (nx4 - 1)];
       }
-      for (int k = l8; k < K; k += 8) XT[k * LD + srow] = xrow[k];
+    }
+  };
+  auto commit = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < NT_ALL; ++i) {
+      const int q = tid + 256 * i;
+      if (q < ny4) {
+        const int e = 4 * q, f = e >> 5, r = e & 31;
+        float* d = YT + f * LD + r;
+        d[0] = yq[i].x; d[1] = yq[i].y; d[2] = yq[i].z; d[3] = yq[i].w;
+      }
+    }
+    if (!tk.x_rowmajor) {
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        const int q = tid + 256 * i;
+        if (q < nx4) {
+          const int e = 4 * q, f = e >> 5, r = e & 31;
+          float* d = XT + f * LD + r;
+          d[0] = xq[i].x; d[1] = xq[i].y; d[2] = xq[i].z; d[3] = xq[i].w;
+        }
+      }
     } else {
-      for (int i = tid; i < K * 32; i += 256) {
-        const int f = i >> 5, r = i & 31;
-        XT[f * LD + r] = tk.x[((long)it * K) * 32 + i];
-      }
+      const int srow = tid >> 3, l8 = tid & 7;
+      DenseTask g;
+      g.Rm = tk.Rm; g.E = tk.E; g.A = tk.A; g.xshare = tk.xshare; g.idx = tk.idx;
+      const float* xrow = tk.x + gather_row(g, it * 32 + srow) * tk.x_ld;
+      for (int k = l8; k < K; k += 8) XT[k * LD + srow] = xrow[k];
     }
-    __syncthreads();
+  };
+
+  const int ntiles = tk.rows / 32;
+  int it = blockIdx.x;
+  if (it < ntiles) {
+    issue(it);
+    commit(it);
+  }
+  __syncthreads();
+  for (; it < ntiles; it += gridDim.x) {
+    const int itn = it + gridDim.x;
+    if (itn < ntiles) issue(itn);
     // ---- dW[k][n] += sum_rows x[row][k] * y[row][n]
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
@@ -243,6 +332,9 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
         }
       }
     }
+    __syncthreads();  // all readers of the staged tiles are done
+    if (itn < ntiles) commit(itn);
+    __syncthreads();
   }
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
 #pragma unroll
@@ -264,17 +356,31 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
   }
 }
 
-template <int NB, int NTW>
-int launch_dense(const DenseTask& tk, hipStream_t s) {
-  const size_t lb = tk.x_rowmajor ? (size_t)32 * (16 * NB + 1) * sizeof(float) : 0;
+template <int NB, int NTW, bool RM, bool FULLK>
+int launch_dense_rm(const DenseTask& tk, hipStream_t s) {
+  const size_t lb = RM ? (size_t)32 * (16 * NB + 1) * sizeof(float) : 0;
   if (lb > 0)
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_kernel<NB, NTW>,
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_kernel<NB, NTW, RM, FULLK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
   int blocks = tk.rows / 32;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL((rec_dense_kernel<NB, NTW>), dim3(blocks), dim3(256), lb, s, tk);
+  hipLaunchKernelGGL((rec_dense_kernel<NB, NTW, RM, FULLK>), dim3(blocks), dim3(256), lb, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
+}
+
+template <int NB, int NTW>
+int launch_dense(const DenseTask& tk, hipStream_t s) {
+  if (tk.x_rowmajor) {
+    if (NTW == 1) return launch_dense_rm<NB, 1, true, false>(tk, s);  // external observations feed 128-wide torsos only
+    mava_set_error("mava_rec_dense_f32: row-major input is instantiated for N <= 128 only");
+    return MAVA_EARG(9);
+  }
+  if (tk.K == 16 * NB) return launch_dense_rm<NB, NTW, false, true>(tk, s);
+  if (NB <= 2 && NTW == 1) return launch_dense_rm<(NB <= 2 ? NB : 2), 1, false, false>(tk, s);  // n_out-wide inputs
+  mava_set_error("mava_rec_dense_f32: T32 input width K=%d is not instantiated for N=%d (T32 inputs: K <= 32, or K in "
+                 "{64,96,128,192,288,384} with N <= 128, or K = 128 / 192 with N <= 384 / 256)", tk.K, tk.N);
+  return MAVA_EARG(9);
 }
 
 template <int KT, int NTW>

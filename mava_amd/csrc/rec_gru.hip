@@ -80,20 +80,27 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
     }
   }
 
-  for (int t = 0; t < tk.T; ++t) {
-    const long tile = (long)t * tiles_per_t + mt;
-    const float* git = tk.gi + tile * G3 * 32;
-    f32x16 ar, az, an;
-    float gin[16];
+  // gate pre-activations of the CURRENT step (loaded one step ahead, under the previous step's MFMAs)
+  float gr[16], gz[16], gin[16];
+  auto load_gi = [&](int t) {
+    const float* git = tk.gi + ((long)t * tiles_per_t + mt) * G3 * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2);
-      ar[r] = git[(long)f * 32 + j];
-      az[r] = git[(long)(MLP_H + f) * 32 + j];
+      gr[r] = git[(long)f * 32 + j];
+      gz[r] = git[(long)(MLP_H + f) * 32 + j];
       gin[r] = git[(long)(2 * MLP_H + f) * 32 + j];
-      an[r] = bn[r];
     }
+  };
+  load_gi(0);
+  for (int t = 0; t < tk.T; ++t) {
+    const long tile = (long)t * tiles_per_t + mt;
+    f32x16 ar, az, an;
+    float gn[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ar[r] = gr[r]; az[r] = gz[r]; gn[r] = gin[r]; an[r] = bn[r]; }
     const bool rs_next = (t + 1 < tk.T) ? (tk.done[ext_row(tk, t + 1, m)] != 0) : false;
+    if (t + 1 < tk.T) load_gi(t + 1);  // in flight during the 192 MFMAs below
     __syncthreads();  // HT (masked h entering step t) complete
     {
       const float* hb = HT + h * LDT + j;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
       const int f = fb + (r & 3) + 8 * (r >> 2);
       const float rr = sigmoidf_(ar[r]);
       const float zz = sigmoidf_(az[r]);
-      const float nn = tanhf(gin[r] + rr * an[r]);
+      const float nn = tanhf(gn[r] + rr * an[r]);
       hn[r] = (1.0f - zz) * nn + zz * hp[r];
       tk.hs[(tile * MLP_H + f) * 32 + j] = hn[r];
       if (tk.hprev != nullptr) tk.hprev[(tile * MLP_H + f) * 32 + j] = hp[r];
@@ -159,20 +166,32 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) dhc[r] = 0.0f;
 
-  for (int t = tk.T - 1; t >= 0; --t) {
+  // per-step inputs of the CURRENT step, loaded one step ahead (under the previous step's 192 MFMAs)
+  float i_r[16], i_z[16], i_n[16], i_hl[16], i_hp[16], i_dh[16];
+  auto load_step = [&](int t) {
     const long tile = (long)t * tiles_per_t + mt;
     const float* sv = tk.saved + tile * (4 * MLP_H) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fb + (r & 3) + 8 * (r >> 2);
+      i_r[r] = sv[(long)f * 32 + j];
+      i_z[r] = sv[(long)(MLP_H + f) * 32 + j];
+      i_n[r] = sv[(long)(2 * MLP_H + f) * 32 + j];
+      i_hl[r] = sv[(long)(3 * MLP_H + f) * 32 + j];
+      i_hp[r] = tk.hprev[(tile * MLP_H + f) * 32 + j];
+      i_dh[r] = tk.dh_out[(tile * MLP_H + f) * 32 + j];
+    }
+  };
+  load_step(tk.T - 1);
+  for (int t = tk.T - 1; t >= 0; --t) {
+    const long tile = (long)t * tiles_per_t + mt;
     const bool rs = tk.done[ext_row(tk, t, m)] != 0;
     float dhp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2);
-      const float rr = sv[(long)f * 32 + j];
-      const float zz = sv[(long)(MLP_H + f) * 32 + j];
-      const float nn = sv[(long)(2 * MLP_H + f) * 32 + j];
-      const float hl = sv[(long)(3 * MLP_H + f) * 32 + j];
-      const float hp = tk.hprev[(tile * MLP_H + f) * 32 + j];
-      const float dh = tk.dh_out[(tile * MLP_H + f) * 32 + j] + dhc[r];
+      const float rr = i_r[r], zz = i_z[r], nn = i_n[r], hl = i_hl[r], hp = i_hp[r];
+      const float dh = i_dh[r] + dhc[r];
       const float dn = dh * (1.0f - zz);
       const float dz = dh * (hp - nn);
       dhp[r] = dh * zz;
@@ -193,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
       DG[(MLP_H + f) * LDT + j] = dz_pre;
       DG[(2 * MLP_H + f) * LDT + j] = dghn;
     }
+    if (t > 0) load_step(t - 1);  // in flight during the MFMAs below
     __syncthreads();
     f32x16 acc;
 #pragma unroll

@@ -27,7 +27,7 @@ def _from_t32(flat, rows, N):
 
 
 @pytest.mark.parametrize("K,N,relu,gated", [(128, 384, False, False), (128, 128, True, False), (128, 13, False, False),
-                                             (384, 128, False, True), (5, 128, False, True), (155, 128, True, False)])
+                                             (384, 128, False, True), (5, 128, False, True), (192, 128, True, False), (128, 256, False, False)])
 def test_rec_dense_t32(dev, K, N, relu, gated):
     from mava_amd._lib import check, lib, ptr, stream_ptr
 
@@ -271,3 +271,15 @@ def test_rec_learner_update_matches_oracle(dev, system, U):
     out = learn(L.learner_state())
     torch.cuda.synchronize()
     assert out.train_metrics["total_loss"].shape == (1, 2, U, K, M) and torch.isfinite(out.train_metrics["total_loss"]).all()
+
+
+def test_rec_dense_rejects_unsupported_t32_width(dev):
+    """T32 inputs wider than 32 features must be a multiple of 16 (internal widths are 128/384/n_out): loud error."""
+    from mava_amd._lib import MavaHipError, check, lib, ptr, stream_ptr
+
+    x = torch.zeros(32 * 155, device=dev)
+    w = torch.zeros(155 * 128, device=dev)
+    y = torch.zeros(32 * 128, device=dev)
+    with pytest.raises(MavaHipError):
+        check(lib().mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, 155, 0, ptr(w), 128, None, None, ptr(y), 155, 128, 32, 0,
+                                       stream_ptr()), "dense")

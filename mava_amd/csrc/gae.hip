@@ -70,7 +70,7 @@ __device__ inline void stf(float* p, const float (&o)[VEC]) {
 // and still reads 256 contiguous bytes per chunk row).  Slabs of L*NC time steps are walked from the end
 // of the rollout to the start; T <= L*NC (the BASELINE shapes) is a single slab.
 template <int VEC, int L, int NC, int LPC>
-__global__ __launch_bounds__(LPC * NC) void gae_kernel(
+__global__ __launch_bounds__(LPC * NC) void gae_kernel_ragged(
     const float* __restrict__ reward, const float* __restrict__ value,
     const uint8_t* __restrict__ done, const float* __restrict__ last_val,
     const uint8_t* __restrict__ last_done, int T, int N, float gamma, float lambda,
@@ -206,14 +206,145 @@ __global__ __launch_bounds__(LPC * NC) void gae_kernel(
   }
 }
 
+
+// Fast path (T % L == 0, so a chunk is either entirely inside the rollout or entirely past its end).
+// The load phase is branch-free and only moves raw bits into registers: out-of-range rows / columns are
+// clamped to valid addresses and masked later, the done bytes are converted after every load of the
+// chunk has been issued (a conversion next to its load makes the compiler wait for memory once per step,
+// i.e. L serial round trips instead of one).  Loads are issued last step first, the order the reverse
+// scan consumes them.  The cross-chunk composition is a fixed-trip predicated loop so its LDS reads are
+// issued ahead of the dependent FMA chain.
+template <int VEC, int L, int NC, int LPC>
+__global__ __launch_bounds__(LPC * NC) void gae_kernel(
+    const float* __restrict__ reward, const float* __restrict__ value,
+    const uint8_t* __restrict__ done, const float* __restrict__ last_val,
+    const uint8_t* __restrict__ last_done, int T, int N, float gamma, float lambda,
+    float* __restrict__ adv, float* __restrict__ tgt) {
+  typedef typename VecT<VEC>::f VF;
+  typedef typename VecT<VEC>::b VB;
+  constexpr int CB = LPC * VEC;
+  __shared__ float sP[NC][CB];
+  __shared__ float sS[NC][CB];
+  __shared__ float sAin[CB];
+
+  const int chunk = threadIdx.x / LPC;
+  const int lc = threadIdx.x - chunk * LPC;
+  const long col = ((long)blockIdx.x * LPC + lc) * VEC;
+  const bool live = col < N;
+  const long colc = live ? col : 0;
+  const bool shifted = last_done != nullptr;
+  const float gl = gamma * lambda;
+  constexpr int slab_len = L * NC;
+  const int n_slab = (T + slab_len - 1) / slab_len;
+
+  if (chunk == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sAin[lc * VEC + i] = 0.0f;
+  }
+
+  for (int slab = n_slab - 1; slab >= 0; --slab) {
+    const int t0 = slab * slab_len + chunk * L;
+    const bool valid = t0 < T;            // whole chunk (T % L == 0)
+    const int tb = valid ? t0 : T - L;    // clamped base row for the loads
+    VF rr[L], vv[L + 1];
+    VB dd[L];
+    {
+      const int t = tb + L;
+      const float* pv = (t < T) ? value + (long)t * N + colc : last_val + colc;
+      vv[L] = *reinterpret_cast<const VF*>(pv);
+    }
+#pragma unroll
+    for (int s = L - 1; s >= 0; --s) {
+      const int t = tb + s;
+      const long off = (long)t * N + colc;
+      const uint8_t* pd = done + off;
+      if (shifted) pd = (t + 1 < T) ? pd + N : last_done + colc;
+      vv[s] = *reinterpret_cast<const VF*>(value + off);
+      rr[s] = *reinterpret_cast<const VF*>(reward + off);
+      dd[s] = *reinterpret_cast<const VB*>(pd);
+    }
+
+    float S[L][VEC], P[L][VEC];
+    float a[VEC], p[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { a[i] = 0.f; p[i] = 1.f; }
+#pragma unroll
+    for (int s = L - 1; s >= 0; --s) {
+      const float* r_ = reinterpret_cast<const float*>(&rr[s]);
+      const float* v_ = reinterpret_cast<const float*>(&vv[s]);
+      const float* vn = reinterpret_cast<const float*>(&vv[s + 1]);
+      const uint8_t* d_ = reinterpret_cast<const uint8_t*>(&dd[s]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float nd = d_[i] ? 0.0f : 1.0f;
+        const float c = gl * nd;
+        const float delta = r_[i] + gamma * vn[i] * nd - v_[i];
+        a[i] = delta + c * a[i];
+        p[i] = c * p[i];
+        S[s][i] = a[i];
+        P[s][i] = p[i];
+      }
+    }
+    // a chunk past the end of the rollout is the identity map
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      sP[chunk][lc * VEC + i] = valid ? p[i] : 1.0f;
+      sS[chunk][lc * VEC + i] = valid ? a[i] : 0.0f;
+    }
+    __syncthreads();
+
+    float ain[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ain[i] = sAin[lc * VEC + i];
+  constexpr int CU_ = NC <= 16 ? NC : 8;
+#pragma unroll CU_
+    for (int k = NC - 1; k >= 1; --k) {
+      VF s4 = *reinterpret_cast<const VF*>(&sS[k][lc * VEC]);
+      VF p4 = *reinterpret_cast<const VF*>(&sP[k][lc * VEC]);
+      const float* s_ = reinterpret_cast<const float*>(&s4);
+      const float* p_ = reinterpret_cast<const float*>(&p4);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) ain[i] = (k > chunk) ? s_[i] + p_[i] * ain[i] : ain[i];
+    }
+
+    if (live && valid) {
+#pragma unroll
+      for (int s = 0; s < L; ++s) {
+        const float* v_ = reinterpret_cast<const float*>(&vv[s]);
+        float oa[VEC], ot[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          oa[i] = S[s][i] + P[s][i] * ain[i];
+          ot[i] = oa[i] + v_[i];
+        }
+        stf<VEC>(adv + (long)(t0 + s) * N + col, oa);
+        stf<VEC>(tgt + (long)(t0 + s) * N + col, ot);
+      }
+    }
+
+    if (slab > 0) {
+      __syncthreads();
+      if (chunk == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sAin[lc * VEC + i] = (valid ? a[i] : 0.0f) + (valid ? p[i] : 1.0f) * ain[i];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int VEC, int L, int NC, int LPC>
 int launch_gae(const float* reward, const float* value, const uint8_t* done, const float* last_val,
                const uint8_t* last_done, int T, int N, float gamma, float lambda, float* adv,
                float* tgt, hipStream_t s) {
   const int cols_per_block = LPC * VEC;
   dim3 grid(mava_cdiv(N, cols_per_block)), block(LPC * NC);
-  hipLaunchKernelGGL((gae_kernel<VEC, L, NC, LPC>), grid, block, 0, s, reward, value, done, last_val,
-                     last_done, T, N, gamma, lambda, adv, tgt);
+  if (T % L == 0)
+    hipLaunchKernelGGL((gae_kernel<VEC, L, NC, LPC>), grid, block, 0, s, reward, value, done, last_val,
+                       last_done, T, N, gamma, lambda, adv, tgt);
+  else
+    hipLaunchKernelGGL((gae_kernel_ragged<VEC, L, NC, LPC>), grid, block, 0, s, reward, value, done, last_val,
+                       last_done, T, N, gamma, lambda, adv, tgt);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
@@ -240,12 +371,10 @@ extern "C" int mava_gae_f32(const float* reward, const float* value, const uint8
   const int align = (N % 4 == 0) ? 4 : ((N % 2 == 0) ? 2 : 1);
   int variant = g_gae_variant;
   if (variant == 0) {
-    // default (tools/gae_sweep.py on MI355X): 16-byte accesses in 128-column strips once there are
-    // >= 128 strips, 32-column strips below that, scalar columns for odd N
-    if (align == 4 && N >= 128 * 128) variant = 43;
-    else if (align == 4 && N >= 32 * 64) variant = 45;
-    else if (align >= 2 && N >= 32 * 64) variant = 24;
-    else variant = 1;
+    // default (tools/gae_sweep.py on MI355X, graph-timed): scalar columns in 32-column strips (one 128-byte
+    // line per time row), 8 chunks of 16 steps - 10.4 us from HBM / 7.2 us from cache at (128, 16384),
+    // next to 9.1 / 5.1 us for a device copy of the same byte count
+    variant = (N >= 32 * 64) ? 13 : 1;
   }
   switch (variant) {
     case 41: if (align == 4) return launch_gae<4, 4, 32, 16>(GAE_ARGS); break;   // CB 64, 512 threads
@@ -260,6 +389,11 @@ extern "C" int mava_gae_f32(const float* reward, const float* value, const uint8
     case 22: if (align >= 2) return launch_gae<2, 4, 32, 32>(GAE_ARGS); break;   // CB 64, 1024 threads
     case 23: if (align >= 2) return launch_gae<2, 16, 8, 64>(GAE_ARGS); break;   // CB 128, 512 threads
     case 11: return launch_gae<1, 8, 16, 64>(GAE_ARGS);                            // CB 64, 1024 threads
+    case 12: return launch_gae<1, 8, 16, 32>(GAE_ARGS);                            // CB 32, 512 threads
+    case 13: return launch_gae<1, 16, 8, 32>(GAE_ARGS);                            // CB 32, 256 threads
+    case 14: return launch_gae<1, 32, 4, 64>(GAE_ARGS);                            // CB 64, 256 threads
+    case 15: return launch_gae<1, 4, 32, 32>(GAE_ARGS);                            // CB 32, 1024 threads
+    case 16: return launch_gae<1, 16, 8, 16>(GAE_ARGS);                            // CB 16, 128 threads
     default: break;
   }
   return launch_gae<1, 16, 8, 64>(GAE_ARGS);  // CB 64, 512 threads (any N)

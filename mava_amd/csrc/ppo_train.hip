@@ -66,7 +66,8 @@ struct TrainTask {
 // LDS carve (floats) computed on the host per launch (din / NO dependent), checked against 160 KiB.
 struct TrainLdsLayout {
   int h1t, h2t, dz2t, yp, dy, xs, misc, end;
-  int ldx;  // row stride of the staged x tile: 32*KT1 + 1 (odd => conflict-free column walks)
+  int ldx;  // row stride of the staged x tile: 32*KT1 + 4 floats (16-byte rows, an odd number of 16-byte slots =>
+            // conflict-free ds_read_b128 row walks in P1 and ds_write_b128 staging)
 };
 
 template <int NO>
@@ -78,9 +79,9 @@ TrainLdsLayout make_layout(int kt1) {
   L.dz2t = L.h2t + tile;
   L.yp = L.dz2t + tile;   // [4][NO][32] partial logits
   L.dy = L.yp + 4 * NO * 32;
-  L.ldx = 32 * kt1 + 1;
-  L.xs = L.dy + NO * 32;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns
-  L.misc = L.xs + 32 * L.ldx + 32;
+  L.ldx = 32 * kt1 + 4;
+  L.xs = (L.dy + NO * 32 + 3) & ~3;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns, 16-byte aligned
+  L.misc = L.xs + 32 * L.ldx;
   L.end = L.misc + 8;
   return L;
 }
@@ -123,31 +124,39 @@ __device__ __forceinline__ long traj_row(const TrainTask& tk, long q, long R) {
   return p * tk.A + a;
 }
 
-// Register-staged copy of one gathered 32-row x tile: 8 threads per row, thread l8 takes columns
-// l8, l8+8, ... (32-byte pieces per row per instruction; every 128-B line is fetched from HBM once and
-// the remaining pieces hit L2).  Plain dword loads with immediate offsets: no per-load address math, no
-// alignment requirement on the row stride.  Issued a whole tile ahead of its use (global -> registers
-// now, registers -> LDS after the consumers of the previous tile have passed their last barrier).
-template <int NR>
-__device__ __forceinline__ void stage_load(const float* __restrict__ xrow_l8, int din, int l8,
-                                           float (&xr)[NR]) {
-  // columns 8i..8i+7 are valid for every thread when i < din/8 (uniform scalar branch, no exec masking);
-  // at most one trailing group is partial
-  const int nfull = din >> 3;
+// Register-staged copy of one gathered 32-row x tile: 8 threads per row, thread l8 takes the V-float pieces
+// l8, l8+8, ... of its row (V = 4 / 2 / 1 by the alignment of the rows: 128 / 64 / 32 bytes per row per
+// instruction).  Immediate offsets only: no per-load address math.  Issued a whole tile ahead of its use
+// (global -> registers now, registers -> LDS after the consumers of the previous tile have passed their last
+// barrier).  nv = pieces per row (din / V); pieces 8i..8i+7 are all valid when i < nv/8 (uniform scalar
+// branch, no exec masking); at most one trailing group is partial.
+template <int V> struct StageVec;
+template <> struct StageVec<1> { typedef float T; };
+template <> struct StageVec<2> { typedef float2 T; };
+template <> struct StageVec<4> { typedef float4 T; };
+
+template <int V, int NR>
+__device__ __forceinline__ void stage_load(const float* __restrict__ xrow_l8, int nv, int l8, float (&xr)[NR]) {
+  typedef typename StageVec<V>::T VT;
+  const VT* src = reinterpret_cast<const VT*>(xrow_l8);  // already offset by V*l8 floats
+  VT* dst = reinterpret_cast<VT*>(&xr[0]);
+  const int nfull = nv >> 3;
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    if (i < nfull) xr[i] = xrow_l8[8 * i];
-    else if (i == nfull && l8 + 8 * i < din) xr[i] = xrow_l8[8 * i];
-    else xr[i] = 0.0f;
+  for (int i = 0; i < NR / V; ++i) {
+    if (i < nfull) dst[i] = src[8 * i];
+    else if (i == nfull && l8 + 8 * i < nv) dst[i] = src[8 * i];
   }
 }
-template <int NR>
-__device__ __forceinline__ void stage_write(float* xs_row_l8, int din, int l8, const float (&xr)[NR]) {
-  const int nfull = din >> 3;
+template <int V, int NR>
+__device__ __forceinline__ void stage_write(float* xs_row_l8, int nv, int l8, const float (&xr)[NR]) {
+  typedef typename StageVec<V>::T VT;
+  VT* dst = reinterpret_cast<VT*>(xs_row_l8);
+  const VT* src = reinterpret_cast<const VT*>(&xr[0]);
+  const int nfull = nv >> 3;
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    if (i < nfull) xs_row_l8[8 * i] = xr[i];
-    else if (i == nfull && l8 + 8 * i < din) xs_row_l8[8 * i] = xr[i];
+  for (int i = 0; i < NR / V; ++i) {
+    if (i < nfull) dst[8 * i] = src[i];
+    else if (i == nfull && l8 + 8 * i < nv) dst[8 * i] = src[i];
   }
 }
 
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   float* const DY = lds + L.dy;
   float* const XS = lds + L.xs;
   float* const misc = lds + L.misc;
-  const int ldx = L.ldx;
+  constexpr int ldx = 32 * KT1 + 4;  // == L.ldx
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
@@ -175,7 +184,11 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   constexpr int NR = 4 * KT1;  // staged floats per thread (32*KT1 columns / 8 threads)
 
   mlp_fill_lds<NO>(lds, tk.params, din, no, 256);
-  for (int i = tid; i < 32 * ldx + 32; i += 256) XS[i] = 0.0f;  // zero padding columns stay zero
+  // Padding columns stay zero for the whole launch except column din, which holds 1.0: "row din" of W1 in the
+  // flat parameter vector IS b1, so layer 1 adds its bias and P5 accumulates db1 (row din of gW1) for free.
+  for (int i = tid; i < 32 * ldx; i += 256) XS[i] = 0.0f;
+  __syncthreads();
+  if (tid < 32) XS[tid * ldx + din] = 1.0f;
   if (ACTOR && tid == 0) {
     // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
     double s1 = 0.0, s2 = 0.0;
@@ -206,8 +219,14 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   float aW3[NOH];
 #pragma unroll
   for (int i = 0; i < NOH; ++i) aW3[i] = 0.0f;
-  float ab3 = 0.0f;   // tid < NO: db3[tid]
-  float ab21 = 0.0f;  // tid < 128: db2[tid]; tid >= 128: db1[tid-128]
+  float ab3 = 0.0f;   // actor: tid < NO: db3[tid]; critic: per-lane partial of db3 (wave 0, half 0)
+  // per-lane partial sums over the rows this lane has seen (lane = row j of every tile), reduced across the 32
+  // row lanes once in the epilogue: db2 for the wave's 16 (r, h) features and, for the one-output critic, dW3
+  float ab2[16], aW3r[ACTOR ? 1 : 16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ab2[r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < (ACTOR ? 1 : 16); ++r) aW3r[r] = 0.0f;
   float loss_a = 0.f, loss_b = 0.f;  // wave 0, half 0 lanes: actor (pg, entropy) / critic (value loss)
 
   const float* const wcol1 = tk.params + 32 * w + j;  // W1[k][32w + j] = wcol1[k*128]
@@ -250,21 +269,31 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     const uint32_t a = qc % (uint32_t)tk.A;
     return (long)p_raw * tk.A + a;
   };
+  const int xv = tk.xv;  // 4 / 2 / 1: widest vector the row alignment allows (uniform)
   auto stage_issue = [&](long fr, float (&xr)[NR]) {
     const uint32_t xrow_idx = (uint32_t)fr / (uint32_t)tk.xshare;  // 32-bit: TE*A < 2^31 is checked on the host
-    const float* xrow = tk.x + (long)xrow_idx * din + l8;
-    stage_load<NR>(xrow, din, l8, xr);
+    const float* xrow = tk.x + (long)xrow_idx * din;
+    if (xv == 4) stage_load<4, NR>(xrow + 4 * l8, din >> 2, l8, xr);
+    else if (xv == 2) stage_load<2, NR>(xrow + 2 * l8, din >> 1, l8, xr);
+    else stage_load<1, NR>(xrow + l8, din, l8, xr);
   };
-  auto stage_commit = [&](const float (&xr)[NR]) { stage_write<NR>(XS + srow * ldx + l8, din, l8, xr); };
+  auto stage_commit = [&](const float (&xr)[NR]) {
+    float* row = XS + srow * ldx;
+    if (xv == 4) stage_write<4, NR>(row + 4 * l8, din >> 2, l8, xr);
+    else if (xv == 2) stage_write<2, NR>(row + 2 * l8, din >> 1, l8, xr);
+    else stage_write<1, NR>(row + l8, din, l8, xr);
+  };
 
   // W1 operand ring depth (batches of 8 k-steps); must divide the batch count 2*KT1
   constexpr int RD = ((2 * KT1) % 3 == 0) ? 3 : (((2 * KT1) % 4 == 0) ? 4 : 2);
   float wr[RD][8];
-  const float* const wcol1h = wcol1 + h * MLP_H;  // W1[k + h][32w + j] = wcol1h[k * 128]
+  // k order inside a batch of 16 inputs: MFMA step s multiplies k = 16b + s (lane half 0) and k = 16b + 8 + s
+  // (half 1), so a lane's eight x operands of a batch are 32 contiguous bytes of its row (two ds_read_b128)
+  const float* const wcol1h = wcol1 + 8 * h * MLP_H;  // W1[k + 8h][32w + j] = wcol1h[k * 128]
 #pragma unroll
   for (int d = 0; d < RD; ++d)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) wr[d][s] = wcol1h[(16 * d + 2 * s) * MLP_H];
+    for (int s = 0; s < 8; ++s) wr[d][s] = wcol1h[(16 * d + s) * MLP_H];
 
   const long ntiles = (R + 31) / 32;
   long it = blockIdx.x;
@@ -297,12 +326,12 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     // ---------------------------------------------------------------- P1: layer 1, tile w
     f32x16 h1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h1[r] = lds[MlpLds<NO>::B1 + fbase + (r & 3) + 8 * (r >> 2)];
+    for (int r = 0; r < 16; ++r) h1[r] = 0.0f;  // b1 enters through the ones column of the x tile
     {
       // W1 operands stream from L2 through a shifting ring of RD batches of 8 k-steps (prefetch distance
       // RD*512 MFMA cycles).  The refill index wraps, so when the loop ends the ring already holds
       // batches 0..RD-1 for the next row tile.  x operands come from the staged LDS tile one batch ahead.
-      const float* xb = XS + j * ldx + h;  // x[row j][k + h]
+      const float* xb = XS + j * ldx + 8 * h;  // x[row j][k + 8h]
       constexpr int NB = 2 * KT1;          // batches of 8 k-steps (16 inputs)
       static_assert(NB % RD == 0, "ring depth must divide the batch count");
       // Ring slot d holds batch g*RD + d (W1 operands from L2) and xo[d] its x operands (LDS).  Slots are
@@ -312,16 +341,24 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       // Rows k >= din of "W1" are the bias / W2 words that follow it in the flat parameter vector: finite
       // values that meet the zero padding of the x tile, so no clamp and no per-load address math.
       float xo[RD][8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) xo[0][s] = xb[2 * s];
+      {
+        const float4 v0 = *reinterpret_cast<const float4*>(xb), v1 = *reinterpret_cast<const float4*>(xb + 4);
+        xo[0][0] = v0.x; xo[0][1] = v0.y; xo[0][2] = v0.z; xo[0][3] = v0.w;
+        xo[0][4] = v1.x; xo[0][5] = v1.y; xo[0][6] = v1.z; xo[0][7] = v1.w;
+      }
 #pragma unroll 1
       for (int g = 0; g < NB / RD; ++g) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) {
           const int b = g * RD + d;
           const int bn = (b + 1 < NB) ? (b + 1) : b;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) xo[(d + 1) % RD][s] = xb[16 * bn + 2 * s];
+          {
+            const float4 v0 = *reinterpret_cast<const float4*>(xb + 16 * bn);
+            const float4 v1 = *reinterpret_cast<const float4*>(xb + 16 * bn + 4);
+            float(&xn)[8] = xo[(d + 1) % RD];
+            xn[0] = v0.x; xn[1] = v0.y; xn[2] = v0.z; xn[3] = v0.w;
+            xn[4] = v1.x; xn[5] = v1.y; xn[6] = v1.z; xn[7] = v1.w;
+          }
 #pragma unroll
           for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[d][s], xo[d][s], h1);
           // refill the slot consumed ONE batch ago (its MFMAs have retired: no write-after-read wait on
@@ -330,13 +367,13 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
           bf = (bf >= NB) ? (bf - NB) : bf;
           const float* wb = wcol1h + bf * (16 * MLP_H);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) wr[(d + RD - 1) % RD][s] = wb[(2 * s) * MLP_H];
+          for (int s = 0; s < 8; ++s) wr[(d + RD - 1) % RD][s] = wb[s * MLP_H];
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       // trailing refill of the last slot (batch NB-1+RD wraps to head batch RD-1 of the next tile)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) wr[RD - 1][s] = wcol1h[(16 * (RD - 1) + 2 * s) * MLP_H];
+      for (int s = 0; s < 8; ++s) wr[RD - 1][s] = wcol1h[(16 * (RD - 1) + s) * MLP_H];
     }
     STAMP(12);
 #pragma unroll
@@ -480,7 +517,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       for (int o = 0; o < NO; ++o) acc = fmaf(w3[o], dy[o], acc);
       dz[r] = (h2[r] > 0.0f) ? acc : 0.0f;
       DZ2T[f * LDT + j] = dz[r];
+      ab2[r] += dz[r];
+      if (!ACTOR) aW3r[r] = fmaf(h2[r], dy[0], aW3r[r]);
     }
+    if (!ACTOR && w == 0 && h == 0) ab3 += dy[0];
     STAMP(2);
     __syncthreads();  // C
 
@@ -508,8 +548,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    {
-      // dW3[f][o] += sum_rows h2[f][row] * dy[o][row];  db3, db2
+    if (ACTOR) {
+      // dW3[f][o] += sum_rows h2[f][row] * dy[o][row];  db3
       // all loads of an 8-row chunk are issued before their first use (one LDS latency per chunk)
       const float* hrow = H2T + sf * LDT;
 #pragma unroll
@@ -539,19 +579,6 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
           for (int row = 0; row < 16; ++row) s += v[row];
         }
         ab3 += s;
-      }
-      if (tid < 128) {
-        const float* zr = DZ2T + tid * LDT;
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float v[16];
-#pragma unroll
-          for (int row = 0; row < 16; ++row) v[row] = zr[16 * c + row];
-#pragma unroll
-          for (int row = 0; row < 16; row += 2) { s0 += v[row]; s1 += v[row + 1]; }
-        }
-        ab21 += s0 + s1;
       }
     }
     STAMP(3);
@@ -599,19 +626,6 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
         for (int s = 0; s < 16; ++s) gW1[t] = MFMA32(xa[(2 * s) * ldx + 32 * t], bz[s], gW1[t]);
         __builtin_amdgcn_sched_barrier(0);  // keep the next tile's LDS reads from piling up in VGPRs
       }
-      if (tid >= 128) {
-        const float* zr = DZ1T + (tid - 128) * LDT;
-        float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float v[16];
-#pragma unroll
-          for (int row = 0; row < 16; ++row) v[row] = zr[16 * c + row];
-#pragma unroll
-          for (int row = 0; row < 16; row += 2) { s0 += v[row]; s1 += v[row + 1]; }
-        }
-        ab21 += s0 + s1;
-      }
     }
     STAMP(6);
     __syncthreads();  // E: every exchange tile and the x tile are free
@@ -637,20 +651,40 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = mlp_feat(t, r, h);
-      if (k < din) slab[k * MLP_H + 32 * w + j] = gW1[t][r];
+      if (k <= din) slab[k * MLP_H + 32 * w + j] = gW1[t][r];  // row din = db1 (oB1 == din * 128)
     }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) slab[oW2 + mlp_feat(t, r, h) * MLP_H + 32 * w + j] = gW2[t][r];
+  // per-lane partials -> sums over the 32 row lanes of each half (fixed xor tree: reproducible)
 #pragma unroll
-  for (int i = 0; i < NOH; ++i) {
-    const int o = 2 * i + og;
-    if (o < no) slab[oW3 + sf * no + o] = aW3[i];
+  for (int r = 0; r < 16; ++r) {
+    float v = ab2[r];
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (j == 0) slab[oB2 + fbase + (r & 3) + 8 * (r >> 2)] = v;
   }
-  if (tid < no) slab[oB3 + tid] = ab3;
-  if (tid < 128) slab[oB2 + tid] = ab21;
-  else slab[oB1 + (tid - 128)] = ab21;
+  if (ACTOR) {
+#pragma unroll
+    for (int i = 0; i < NOH; ++i) {
+      const int o = 2 * i + og;
+      if (o < no) slab[oW3 + sf * no + o] = aW3[i];
+    }
+    if (tid < no) slab[oB3 + tid] = ab3;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = aW3r[r];
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (j == 0) slab[oW3 + fbase + (r & 3) + 8 * (r >> 2)] = v;
+    }
+    float v = ab3;
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (tid == 0) slab[oB3] = v;
+  }
   if (w == 0) {
     for (int o = 32; o > 0; o >>= 1) {
       loss_a += __shfl_down(loss_a, o, 64);
@@ -686,7 +720,7 @@ int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
 
 template <int NO, bool ACTOR>
 int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
-  const int kt = (tk.din + 31) / 32;
+  const int kt = tk.din / 32 + 1;  // 32*kt > din: the x tile always has a spare column for the ones (bias) input
 #ifdef MAVA_FAST_BUILD  // developer iteration: only the BASELINE config-2 instantiations
   if (kt == 3) return launch_train<NO, 3, ACTOR>(tk, n_slab, s);
   if (kt == 9) return launch_train<NO, 9, ACTOR>(tk, n_slab, s);
@@ -701,7 +735,7 @@ int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
     case 5: case 6: return launch_train<NO, 6, ACTOR>(tk, n_slab, s);
     case 7: case 8: case 9: return launch_train<NO, 9, ACTOR>(tk, n_slab, s);
     default:
-      mava_set_error("ppo_train: input width %d > 288 is not instantiated", tk.din);
+      mava_set_error("ppo_train: input width %d > 287 is not instantiated", tk.din);
       return MAVA_EARG(9);
   }
 #endif

@@ -77,12 +77,13 @@ TrainLdsLayout make_layout(int kt1) {
   L.h1t = MlpLds<NO>::END;
   L.h2t = L.h1t + tile;   // h2^T, later dz1^T (after the P4 sweeps, behind an extra barrier)
   L.dz2t = L.h2t + tile;
-  L.yp = L.dz2t + tile;   // [4][NO][32] partial logits
-  L.dy = L.yp + 4 * NO * 32;
+  L.yp = L.dz2t + tile;   // [4 waves][32 rows][NO + 1] partial logits
+  L.dy = L.yp + 4 * 32 * (NO + 1);
   L.ldx = 32 * kt1 + 4;
-  L.xs = (L.dy + NO * 32 + 3) & ~3;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns, 16-byte aligned
-  L.misc = L.xs + 32 * L.ldx;
-  L.end = L.misc + 8;
+  // dy: [32 outputs (rows >= NO stay zero)][33] - an MFMA operand both ways (k = output for dz2, k = row for dW3)
+  L.xs = (L.dy + 32 * LDT + 3) & ~3;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns, 16-byte aligned
+  L.misc = L.xs + 32 * L.ldx;  // 16-byte aligned (xs and 32*ldx are)
+  L.end = L.misc + 16;
   return L;
 }
 
@@ -115,52 +116,59 @@ __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict_
   }
 }
 
-// flat trajectory row (t*E+e)*A + a of agent-row q of the minibatch
-__device__ __forceinline__ long traj_row(const TrainTask& tk, long q, long R) {
-  const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));  // R < 2^31 is checked on the host
-  const uint32_t b = qc / (uint32_t)tk.A;
-  const uint32_t a = qc - b * (uint32_t)tk.A;
-  const long p = tk.idx ? (long)tk.idx[b] : tk.idx_base + (long)b;
-  return p * tk.A + a;
-}
-
 // Register-staged copy of one gathered 32-row x tile: 8 threads per row, thread l8 takes the V-float pieces
-// l8, l8+8, ... of its row (V = 4 / 2 / 1 by the alignment of the rows: 128 / 64 / 32 bytes per row per
-// instruction).  Immediate offsets only: no per-load address math.  Issued a whole tile ahead of its use
-// (global -> registers now, registers -> LDS after the consumers of the previous tile have passed their last
-// barrier).  nv = pieces per row (din / V); pieces 8i..8i+7 are all valid when i < nv/8 (uniform scalar
-// branch, no exec masking); at most one trailing group is partial.
-template <int V> struct StageVec;
-template <> struct StageVec<1> { typedef float T; };
-template <> struct StageVec<2> { typedef float2 T; };
-template <> struct StageVec<4> { typedef float4 T; };
-
+// l8, l8+8, ... of its row (V = 4 when the rows are 16-byte aligned: 128 bytes per row per instruction; else 1).
+// Issued a whole tile ahead of its use (global -> registers now, registers -> LDS after the consumers of the
+// previous tile have passed their last barrier).  Branch-free and single-path on purpose: a piece past the end
+// of the row (nv = pieces per row) is loaded from the start of the row instead and stored to a dummy LDS slot,
+// so there is no exec masking, and no merge of differently-allocated registers that would force the compiler to
+// wait for the loads right after issuing them.
 template <int V, int NR>
-__device__ __forceinline__ void stage_load(const float* __restrict__ xrow_l8, int nv, int l8, float (&xr)[NR]) {
-  typedef typename StageVec<V>::T VT;
-  const VT* src = reinterpret_cast<const VT*>(xrow_l8);  // already offset by V*l8 floats
-  VT* dst = reinterpret_cast<VT*>(&xr[0]);
-  const int nfull = nv >> 3;
+__device__ __forceinline__ void stage_load(const float* __restrict__ xrow, int nv, int l8, float (&xr)[NR]) {
 #pragma unroll
   for (int i = 0; i < NR / V; ++i) {
-    if (i < nfull) dst[i] = src[8 * i];
-    else if (i == nfull && l8 + 8 * i < nv) dst[i] = src[8 * i];
+    const int c = l8 + 8 * i;
+    const int cc = (c < nv) ? c : 0;
+    if (V == 4) {
+      const float4 v = reinterpret_cast<const float4*>(xrow)[cc];
+      xr[4 * i + 0] = v.x; xr[4 * i + 1] = v.y; xr[4 * i + 2] = v.z; xr[4 * i + 3] = v.w;
+    } else {
+      xr[i] = xrow[cc];
+    }
   }
 }
 template <int V, int NR>
-__device__ __forceinline__ void stage_write(float* xs_row_l8, int nv, int l8, const float (&xr)[NR]) {
-  typedef typename StageVec<V>::T VT;
-  VT* dst = reinterpret_cast<VT*>(xs_row_l8);
-  const VT* src = reinterpret_cast<const VT*>(&xr[0]);
-  const int nfull = nv >> 3;
+__device__ __forceinline__ void stage_write(float* xs_row, float* dummy, int nv, int l8, const float (&xr)[NR]) {
 #pragma unroll
   for (int i = 0; i < NR / V; ++i) {
-    if (i < nfull) dst[8 * i] = src[i];
-    else if (i == nfull && l8 + 8 * i < nv) dst[8 * i] = src[i];
+    const int c = l8 + 8 * i;
+    float* q = (c < nv) ? (xs_row + V * c) : dummy;
+    if (V == 4) {
+      *reinterpret_cast<float4*>(q) = make_float4(xr[4 * i + 0], xr[4 * i + 1], xr[4 * i + 2], xr[4 * i + 3]);
+    } else {
+      *q = xr[i];
+    }
   }
 }
 
-template <int NO, int KT1, bool ACTOR>
+// All-reduce over aligned groups of G consecutive lanes (G = 8, 16, 32) on the VALU's DPP path: quad xor 1,
+// quad xor 2, then mirrored halves (lane i <-> G-1-i pairs the two already-reduced halves) - no LDS round trips
+// up to 16 lanes; the last step of a 32-lane group crosses DPP rows and uses a lane permute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int G, typename Op>
+__device__ __forceinline__ float group_allreduce(float v, Op op) {
+  v = op(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = op(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+  if (G >= 8) v = op(v, dpp_f<0x141>(v));   // row_half_mirror
+  if (G >= 16) v = op(v, dpp_f<0x140>(v));  // row_mirror
+  if (G >= 32) v = op(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+
+template <int NO, int KT1, bool ACTOR, int XV>
 __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLdsLayout L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const W2s = lds + MlpLds<NO>::W2;
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   // Padding columns stay zero for the whole launch except column din, which holds 1.0: "row din" of W1 in the
   // flat parameter vector IS b1, so layer 1 adds its bias and P5 accumulates db1 (row din of gW1) for free.
   for (int i = tid; i < 32 * ldx; i += 256) XS[i] = 0.0f;
+  for (int i = tid; i < 32 * LDT; i += 256) DY[i] = 0.0f;  // output rows >= NO of the dy tile stay zero
   __syncthreads();
   if (tid < 32) XS[tid * ldx + din] = 1.0f;
   if (ACTOR && tid == 0) {
@@ -203,6 +212,9 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   const float adv_mean = ACTOR ? misc[0] : 0.0f;
   const float adv_rstd = ACTOR ? misc[1] : 0.0f;
 
+  const float* const wcol1 = tk.params + 32 * w + j;  // W1[k][32w + j] = wcol1[k*128]
+  const int fbase = 32 * w + 4 * h;                   // + (r&3) + 8*(r>>2)
+
   // persistent MFMA accumulators: wave w owns output columns [32w, 32w+32) of dW1 and dW2
   f32x16 gW1[KT1], gW2[4];
 #pragma unroll
@@ -214,12 +226,25 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
 #pragma unroll
     for (int r = 0; r < 16; ++r) gW2[t][r] = 0.0f;
   // per-thread accumulators of the small gradients
-  constexpr int NOH = (NO + 1) / 2;
-  const int sf = tid & 127, og = tid >> 7;  // dW3: feature sf, outputs o = 2i + og
-  float aW3[NOH];
+  f32x16 gW3;  // actor: gW3^T[o][32w + j] (MFMA accumulator, rows o < NO meaningful)
 #pragma unroll
-  for (int i = 0; i < NOH; ++i) aW3[i] = 0.0f;
-  float ab3 = 0.0f;   // actor: tid < NO: db3[tid]; critic: per-lane partial of db3 (wave 0, half 0)
+  for (int r = 0; r < 16; ++r) gW3[r] = 0.0f;
+  // A operands of the head product logits^T[o][row] = sum_f W3[f][o] h2^T[f][row] over the wave's 32 features:
+  // k-step r pairs the features of accumulator register r in both lane halves, so B is h2[r] straight from the
+  // layer-2 accumulator.  Actor: lane i = output o (zero for o >= NO).  Critic: every lane carries W3[f] (all
+  // result rows equal; row 0 is read), which is also the factor of dz2 = W3[f] * dy.
+  float w3h[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int f = fbase + (r & 3) + 8 * (r >> 2);
+    w3h[r] = ACTOR ? ((j < NO) ? W3s[f * NO + j] : 0.0f) : W3s[f];
+  }
+  // actor: this lane's A operands of the dz2 product, W3[32w + j][2s + h]
+  float w3a[ACTOR ? NO / 2 : 1];
+#pragma unroll
+  for (int s2 = 0; s2 < (ACTOR ? NO / 2 : 1); ++s2)
+    w3a[s2] = ACTOR ? W3s[(32 * w + j) * NO + 2 * s2 + h] : 0.0f;
+  float ab3 = 0.0f;   // per-lane partial of db3 (actor: output lo over this lane's rows; critic: wave 0, half 0)
   // per-lane partial sums over the rows this lane has seen (lane = row j of every tile), reduced across the 32
   // row lanes once in the epilogue: db2 for the wave's 16 (r, h) features and, for the one-output critic, dW3
   float ab2[16], aW3r[ACTOR ? 1 : 16];
@@ -229,63 +254,76 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   for (int r = 0; r < (ACTOR ? 1 : 16); ++r) aW3r[r] = 0.0f;
   float loss_a = 0.f, loss_b = 0.f;  // wave 0, half 0 lanes: actor (pg, entropy) / critic (value loss)
 
-  const float* const wcol1 = tk.params + 32 * w + j;  // W1[k][32w + j] = wcol1[k*128]
-  const int fbase = 32 * w + 4 * h;                   // + (r&3) + 8*(r>>2)
 
   // per-row inputs of the loss (row j of the tile), prefetched one tile ahead
   // NOTHING in the prefetch path may do arithmetic on a value it has just loaded: the compiler places the
   // vmcnt wait at the first use, and vmcnt retires in order, so one early use exposes the whole HBM gather.
-  constexpr int NMB = ACTOR ? (NO + 3) / 4 : 1;  // raw mask bytes, 4 per register
-  struct RowIn {
-    int act;
-    float f0, f1;        // actor: old_logp, advantage ; critic: old_value, target
-    uint8_t mraw[4 * NMB];  // raw action-mask bytes (decoded in P3)
-  };
-  auto load_row = [&](long fr) {
-    RowIn ri;
+  // Actor: the loss of a tile is computed ONCE, lane-parallel: wave w owns rows [8w, 8w+8), NO lanes per row
+  // (lane = (row, output)), NP passes of 64/NO rows.  Critic: one output, every lane computes row j itself.
+  constexpr int NP = ACTOR ? NO / 8 : 1;       // passes
+  constexpr int GR = ACTOR ? 64 / NO : 32;     // rows per pass (actor)
+  const int lo = ACTOR ? (lane & (NO - 1)) : 0;  // this lane's output index (actor)
+  auto loss_row = [&](int q) -> int { return ACTOR ? (8 * w + q * GR + lane / NO) : j; };
+  // per-row loss inputs (plain scalars, no aggregates: they must stay in registers)
+  //   act: action ; f0, f1: actor old_logp, advantage / critic old_value, target ; m: raw mask byte of output lo
+  auto load_row = [&](long fr, int& act, float& f0, float& f1, uint32_t& m) {
     if (ACTOR) {
-      ri.act = tk.action[fr];
-      ri.f0 = tk.old_logp[fr];
-      ri.f1 = tk.adv[fr];
-      const uint8_t* mk = tk.mask ? (tk.mask + fr * no) : nullptr;
-#pragma unroll
-      for (int o = 0; o < 4 * NMB; ++o) ri.mraw[o] = (mk != nullptr && o < no) ? mk[o] : (uint8_t)1;
+      act = tk.action[fr];
+      f0 = tk.old_logp[fr];
+      f1 = tk.adv[fr];
+      const uint8_t* mk = (tk.mask != nullptr && lo < no) ? (tk.mask + fr * no + lo) : nullptr;
+      m = 1u;
+      if (mk != nullptr) m = *mk;
     } else {
-      ri.act = 0;
-      ri.f0 = tk.old_value[fr];
-      ri.f1 = tk.targets[fr];
-      ri.mraw[0] = 0;
+      act = 0;
+      f0 = tk.old_value[fr];
+      f1 = tk.targets[fr];
+      m = 0u;
     }
-    return ri;
   };
-  // minibatch index gather, raw: returns idx[b] (or the identity) without touching it
-  auto gather_idx = [&](long q, uint32_t& b_out) -> int32_t {
-    const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));
-    b_out = qc / (uint32_t)tk.A;
-    return tk.idx ? tk.idx[b_out] : (int32_t)(tk.idx_base + (long)b_out);
+  // Row cursors: agent-row q = 32*tile + r of the minibatch is (b, a) = (q / A, q % A), index idx[b], trajectory
+  // row idx[b]*A + a.  A thread's q advances by the same 32*gridDim.x every tile, so (b, a) are advanced
+  // incrementally - no integer division inside the tile loop.  Rows past the end clamp to row R-1.
+  const uint32_t Au = (uint32_t)tk.A;
+  const uint32_t q_step = 32u * gridDim.x, b_step = q_step / Au, a_step = q_step % Au;
+  const uint32_t b_last = (uint32_t)(R - 1) / Au, a_last = (uint32_t)(R - 1) % Au;
+  struct Cursor { uint32_t q, b, a; };
+  auto cursor_at = [&](int r) {
+    Cursor c;
+    c.q = 32u * blockIdx.x + (uint32_t)r;
+    c.b = c.q / Au;
+    c.a = c.q - c.b * Au;
+    return c;
   };
-  auto row_of = [&](long q, int32_t p_raw) -> long {
-    const uint32_t qc = (uint32_t)(q < R ? q : (R - 1));
-    const uint32_t a = qc % (uint32_t)tk.A;
-    return (long)p_raw * tk.A + a;
+  auto cursor_advance = [&](Cursor& c) {
+    c.q += q_step; c.b += b_step; c.a += a_step;
+    if (c.a >= Au) { c.a -= Au; c.b += 1u; }
   };
-  const int xv = tk.xv;  // 4 / 2 / 1: widest vector the row alignment allows (uniform)
-  auto stage_issue = [&](long fr, float (&xr)[NR]) {
-    const uint32_t xrow_idx = (uint32_t)fr / (uint32_t)tk.xshare;  // 32-bit: TE*A < 2^31 is checked on the host
-    const float* xrow = tk.x + (long)xrow_idx * din;
-    if (xv == 4) stage_load<4, NR>(xrow + 4 * l8, din >> 2, l8, xr);
-    else if (xv == 2) stage_load<2, NR>(xrow + 2 * l8, din >> 1, l8, xr);
-    else stage_load<1, NR>(xrow + l8, din, l8, xr);
+  // raw index gather at the cursor (the loaded value is NOT touched here) + the agent that goes with it
+  auto cursor_gather = [&](const Cursor& c, int32_t& p_raw, uint32_t& a_out) {
+    const bool in = c.q < (uint32_t)R;
+    const uint32_t b = in ? c.b : b_last;
+    a_out = in ? c.a : a_last;
+    p_raw = tk.idx ? tk.idx[b] : (int32_t)(tk.idx_base + (long)b);
+  };
+  // input row of trajectory row fr = p*A + a is fr / xshare: fr itself (per-agent inputs) or p (one input row
+  // per (t, env), shared by its A agents); 32-bit: TE*A < 2^31 is checked on the host
+  auto stage_row = [&](int32_t p_raw, uint32_t a) -> uint32_t {
+    const uint32_t fr = (uint32_t)p_raw * Au + a;
+    return (tk.xshare == 1) ? fr : ((uint32_t)tk.xshare == Au ? (uint32_t)p_raw : fr / (uint32_t)tk.xshare);
+  };
+  float* const xs_dummy = misc + 4;  // 16 bytes nobody reads
+  auto stage_issue = [&](uint32_t xrow_idx, float (&xr)[NR]) {
+    stage_load<XV, NR>(tk.x + (long)xrow_idx * din, din / XV, l8, xr);
   };
   auto stage_commit = [&](const float (&xr)[NR]) {
-    float* row = XS + srow * ldx;
-    if (xv == 4) stage_write<4, NR>(row + 4 * l8, din >> 2, l8, xr);
-    else if (xv == 2) stage_write<2, NR>(row + 2 * l8, din >> 1, l8, xr);
-    else stage_write<1, NR>(row + l8, din, l8, xr);
+    stage_write<XV, NR>(XS + srow * ldx, xs_dummy, din / XV, l8, xr);
   };
 
-  // W1 operand ring depth (batches of 8 k-steps); must divide the batch count 2*KT1
-  constexpr int RD = ((2 * KT1) % 3 == 0) ? 3 : (((2 * KT1) % 4 == 0) ? 4 : 2);
+  // W1 operand ring depth (batches of 8 k-steps); must divide the batch count 2*KT1.  Up to 96 inputs the whole
+  // slice of W1 a lane ever needs (<= 48 words) stays in registers for the launch: no refills at all.
+  constexpr int RD = (2 * KT1 <= 6) ? (2 * KT1) : (((2 * KT1) % 6 == 0) ? 6 : 4);
+  constexpr bool W1_RESIDENT = (RD == 2 * KT1);
   float wr[RD][8];
   // k order inside a batch of 16 inputs: MFMA step s multiplies k = 16b + s (lane half 0) and k = 16b + 8 + s
   // (half 1), so a lane's eight x operands of a batch are 32 contiguous bytes of its row (two ds_read_b128)
@@ -298,19 +336,36 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   const long ntiles = (R + 31) / 32;
   long it = blockIdx.x;
   float xr[NR];
-  RowIn rin = {};
-  // trajectory rows of the NEXT tile for both thread roles (staging row srow / loss row j): the index
-  // gather runs one tile ahead of the loads that depend on it, two tiles ahead of the compute
-  int32_t ps_next = 0, pj_next = 0;  // RAW idx values of the next tile (staging row srow / loss row j)
+  int r_act[NP] = {}, n_act[NP] = {};
+  float r_f0[NP] = {}, r_f1[NP] = {}, n_f0[NP] = {}, n_f1[NP] = {};
+  uint32_t r_m[NP] = {}, n_m[NP] = {};
+  // The index gather runs one tile ahead of the loads that depend on it, two tiles ahead of the compute:
+  // cs / cl[] are the gather cursors (staging row srow / loss rows), p*_next, a*_next the raw idx value and agent
+  // of the NEXT tile.
+  Cursor cs = cursor_at(srow), cl[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) cl[q] = cursor_at(loss_row(q));
+  int32_t ps_next = 0, pl_next[NP] = {};
+  uint32_t as_next = 0, al_next[NP] = {};
   if (it < ntiles) {
-    stage_issue(traj_row(tk, it * 32 + srow, R), xr);
-    rin = load_row(traj_row(tk, it * 32 + j, R));
+    cursor_gather(cs, ps_next, as_next);
+    stage_issue(stage_row(ps_next, as_next), xr);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      cursor_gather(cl[q], pl_next[q], al_next[q]);
+      load_row((long)pl_next[q] * tk.A + al_next[q], r_act[q], r_f0[q], r_f1[q], r_m[q]);
+    }
     stage_commit(xr);
-    const long itn0 = it + gridDim.x;
-    if (itn0 < ntiles) {
-      uint32_t bb;
-      ps_next = gather_idx(itn0 * 32 + srow, bb);
-      pj_next = gather_idx(itn0 * 32 + j, bb);
+    cursor_advance(cs);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+    if (it + gridDim.x < ntiles) {
+      cursor_gather(cs, ps_next, as_next);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+      cursor_advance(cs);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
     }
   }
   __syncthreads();
@@ -321,7 +376,17 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     const bool valid = (it * 32 + j) < R;
     const long itn = it + gridDim.x;
     const bool have_next = itn < ntiles;
-    RowIn rnext = rin;
+    // Addresses of the next tile's rows, from the idx values gathered one tile ago.  Computed HERE, where every
+    // outstanding load is a tile old: the first use of a loaded value waits for ALL younger loads too (vmcnt is
+    // in order), so after barrier A it would wait for the W1 refills P1 has just issued.
+    // (row numbers, not pointers, are pinned: a pointer through an asm loses its global address space)
+    uint32_t xrow_next = stage_row(ps_next, as_next);
+    uint32_t fr_next[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) fr_next[q] = (uint32_t)pl_next[q] * Au + al_next[q];
+    asm volatile("" : "+v"(xrow_next));
+#pragma unroll
+    for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(fr_next[q]));
 
     // ---------------------------------------------------------------- P1: layer 1, tile w
     f32x16 h1;
@@ -363,37 +428,51 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
           for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[d][s], xo[d][s], h1);
           // refill the slot consumed ONE batch ago (its MFMAs have retired: no write-after-read wait on
           // operands still being read) with batch b-1+RD
-          int bf = b - 1 + RD;
-          bf = (bf >= NB) ? (bf - NB) : bf;
-          const float* wb = wcol1h + bf * (16 * MLP_H);
+          if (!W1_RESIDENT) {
+            int bf = b - 1 + RD;
+            bf = (bf >= NB) ? (bf - NB) : bf;
+            const float* wb = wcol1h + bf * (16 * MLP_H);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) wr[(d + RD - 1) % RD][s] = wb[s * MLP_H];
+            for (int s = 0; s < 8; ++s) wr[(d + RD - 1) % RD][s] = wb[s * MLP_H];
+            // (measured: spreading these loads one behind each MFMA with sched_group_barrier is 9 % slower than
+            // the compiler's clump of eight - left as is)
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       // trailing refill of the last slot (batch NB-1+RD wraps to head batch RD-1 of the next tile)
+      if (!W1_RESIDENT) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) wr[RD - 1][s] = wcol1h[(16 * (RD - 1) + s) * MLP_H];
+        for (int s = 0; s < 8; ++s) wr[RD - 1][s] = wcol1h[(16 * (RD - 1) + s) * MLP_H];
+      }
     }
     STAMP(12);
+    uint32_t relu1 = 0;  // bit r: z1 of accumulator register r is positive (relu' for P4b, no LDS re-read)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       h1[r] = fmaxf(h1[r], 0.0f);
+      relu1 |= (h1[r] > 0.0f) ? (1u << r) : 0u;
       H1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = h1[r];
     }
     STAMP(0);
     __syncthreads();  // A
+    STAMP(13);
     // Next tile's gathers are issued only now: vmcnt retires in order, so issuing them before P1 would
     // put the HBM gather latency in front of every W1 operand wait of P1.
     if (have_next) {
       // idx values were gathered one iteration ago (complete by now); only now are they used
-      stage_issue(row_of(itn * 32 + srow, ps_next), xr);  // global -> registers, committed after barrier E
-      rnext = load_row(row_of(itn * 32 + j, pj_next));
-      const long itnn = itn + gridDim.x;
-      if (itnn < ntiles) {  // raw index gather for the tile after next (first used next iteration)
-        uint32_t bb;
-        ps_next = gather_idx(itnn * 32 + srow, bb);
-        pj_next = gather_idx(itnn * 32 + j, bb);
+      stage_issue(xrow_next, xr);  // global -> registers, committed after barrier E
+      STAMP(14);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+      STAMP(15);
+      if (itn + gridDim.x < ntiles) {  // raw index gather for the tile after next (first used next iteration)
+        cursor_gather(cs, ps_next, as_next);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+        cursor_advance(cs);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
       }
     }
     STAMP(10);
@@ -424,103 +503,118 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     }
     STAMP(11);
     {
-      float part[NO];
+      f32x16 yacc;
 #pragma unroll
-      for (int o = 0; o < NO; ++o) part[o] = 0.0f;
+      for (int r = 0; r < 16; ++r) yacc[r] = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         h2[r] = fmaxf(h2[r], 0.0f);
-        const int f = fbase + (r & 3) + 8 * (r >> 2);
-        H2T[f * LDT + j] = h2[r];
-        const float* w3 = W3s + f * NO;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) part[o] = fmaf(h2[r], w3[o], part[o]);
+        H2T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = h2[r];
       }
 #pragma unroll
-      for (int o = 0; o < NO; ++o) {
-        const float v = part[o] + __shfl_xor(part[o], 32, 64);
-        if (h == 0) YP[(w * NO + o) * 32 + j] = v;
+      for (int r = 0; r < 16; ++r) yacc = MFMA32(w3h[r], h2[r], yacc);
+      // partial logits of this wave: register r of lane (row j, half h) is output (r&3) + 8(r>>2) + 4h
+      if (ACTOR) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if ((r & 3) + 8 * (r >> 2) + 4 < NO || (r & 3) + 8 * (r >> 2) < NO) {
+            if (o < NO) YP[(w * 32 + j) * (NO + 1) + o] = yacc[r];
+          }
+        }
+      } else {
+        if (h == 0) YP[(w * 32 + j) * (NO + 1)] = yacc[0];
       }
     }
     STAMP(1);
     __syncthreads();  // B
 
     // ---------------------------------------------------------------- P3: loss, dlogits, dz2
-    float dy[NO];
-    {
-      float y[NO];
+    f32x16 dz;  // dz2 of tile w
+    if (ACTOR) {
+      const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
 #pragma unroll
-      for (int o = 0; o < NO; ++o)
-        y[o] = (((YP[(0 * NO + o) * 32 + j] + YP[(1 * NO + o) * 32 + j]) + YP[(2 * NO + o) * 32 + j]) +
-                YP[(3 * NO + o) * 32 + j]) + lds[MlpLds<NO>::B3 + o];
-      if (ACTOR) {
-        uint32_t mbits = 0;
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-          if (rin.mraw[o]) mbits |= (1u << o);
-        Categorical<NO> cat;
-        cat.build_bits(y, mbits, no);
-        const int act = rin.act;
-        float lp = 0.0f;
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-          if (o == act) lp = cat.logp[o];
-        const float gae = (rin.f1 - adv_mean) * adv_rstd;
-        const float ratio = expf(lp - rin.f0);
-        const float lo = 1.0f - tk.clip_eps, hi = 1.0f + tk.clip_eps;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
+      for (int q = 0; q < NP; ++q) {
+        const int row = loss_row(q);
+        const bool rvalid = (it * 32 + row) < R;
+        const float* yp = YP + row * (NO + 1) + lo;
+        const float y = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) +
+                        lds[MlpLds<NO>::B3 + lo];
+        // masked Categorical over the NO lanes of the row (networks.py:116-124, distributions.py:146-165)
+        const bool legal = (lo < no) && (r_m[q] != 0u);
+        const float z = legal ? y : -FLT_MAX;
+        auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
+        auto add_op = [](float a, float b) { return a + b; };
+        const float mx = group_allreduce<NO>(z, fmax_op);
+        const float se = group_allreduce<NO>(expf(z - mx), add_op);
+        const float logp = z - (mx + logf(se));
+        const float pr = expf(logp);
+        const float ent = group_allreduce<NO>((pr > 0.0f) ? -(pr * logp) : 0.0f, add_op);
+        const int act = r_act[q];
+        const float lp = group_allreduce<NO>((lo == act) ? logp : 0.0f, add_op);
+        const float gae = (r_f1[q] - adv_mean) * adv_rstd;
+        const float ratio = expf(lp - r_f0[q]);
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
         const float l1 = ratio * gae, l2 = rc * gae;
         const float pg = -fminf(l1, l2);
         // d(-min(l1,l2))/d ratio: ties split evenly (lax.min); clip passes gradient inside the range
-        const bool inside = (ratio >= lo) && (ratio <= hi);
+        const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
         const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
         const float g2 = inside ? (1.0f - g1) : 0.0f;
-        const float dlp = valid ? (-(g1 + g2) * gae * ratio * invR) : 0.0f;
-        const float ec = valid ? (tk.ent_coef * invR) : 0.0f;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-          const float oh = (o == act) ? 1.0f : 0.0f;
-          const float pl = (cat.p[o] > 0.0f) ? cat.logp[o] : 0.0f;
-          // -ent_coef * dH/dz_o = +ent_coef * p_o (log p_o + H)
-          dy[o] = dlp * (oh - cat.p[o]) + ec * cat.p[o] * (pl + cat.entropy);
-          if (cat.z[o] == -FLT_MAX) dy[o] = 0.0f;
-        }
-        if (valid && w == 0 && h == 0) {
+        const float dlp = rvalid ? (-(g1 + g2) * gae * ratio * invR) : 0.0f;
+        const float ec = rvalid ? (tk.ent_coef * invR) : 0.0f;
+        const float oh = (lo == act) ? 1.0f : 0.0f;
+        const float pl = (pr > 0.0f) ? logp : 0.0f;
+        // -ent_coef * dH/dz_o = +ent_coef * p_o (log p_o + H)
+        float dyo = dlp * (oh - pr) + ec * pr * (pl + ent);
+        if (z == -FLT_MAX) dyo = 0.0f;
+        DY[lo * LDT + row] = dyo;
+        ab3 += dyo;
+        if (rvalid && lo == 0) {
           loss_a += pg * invR;
-          loss_b += cat.entropy * invR;
+          loss_b += ent * invR;
         }
-      } else {
-        const float v = y[0];
-        const float ov = rin.f0, tg = rin.f1;
-        const float diff = v - ov;
-        const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
-        const float e1 = v - tg, e2 = vclip - tg;
-        const float l1 = e1 * e1, l2 = e2 * e2;
-        const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
-        const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-        const float g2 = inside ? (1.0f - g1) : 0.0f;
-        dy[0] = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2) * invR) : 0.0f;
-        if (valid && w == 0 && h == 0) loss_a += 0.5f * fmaxf(l1, l2) * invR;
       }
-      if (w == 0 && h == 0) {
+      __syncthreads();  // B2: dy of all 32 rows visible
+      // dz2^T[f][row] = sum_o W3[f][o] dy[o][row] on the MFMA (A: this lane's W3 words, kept in registers)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) DY[o * 32 + j] = dy[o];
+      for (int r = 0; r < 16; ++r) dz[r] = 0.0f;
+      const float* dyb = DY + h * LDT + j;  // dy[o = 2s + h][row j]
+#pragma unroll
+      for (int s2 = 0; s2 < NO / 2; ++s2) dz = MFMA32(w3a[s2], dyb[(2 * s2) * LDT], dz);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fbase + (r & 3) + 8 * (r >> 2);
+        dz[r] = (h2[r] > 0.0f) ? dz[r] : 0.0f;
+        DZ2T[f * LDT + j] = dz[r];
+        ab2[r] += dz[r];
+      }
+    } else {
+      const float* yp = YP + j * (NO + 1);
+      const float v = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) +
+                      lds[MlpLds<NO>::B3];
+      const float ov = r_f0[0], tg = r_f1[0];
+      const float diff = v - ov;
+      const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+      const float e1 = v - tg, e2 = vclip - tg;
+      const float l1 = e1 * e1, l2 = e2 * e2;
+      const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+      const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+      const float g2 = inside ? (1.0f - g1) : 0.0f;
+      const float dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2) * invR) : 0.0f;
+      if (valid && w == 0 && h == 0) {
+        loss_a += 0.5f * fmaxf(l1, l2) * invR;
+        ab3 += dy0;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fbase + (r & 3) + 8 * (r >> 2);
+        dz[r] = (h2[r] > 0.0f) ? (w3h[r] * dy0) : 0.0f;
+        DZ2T[f * LDT + j] = dz[r];
+        ab2[r] += dz[r];
+        aW3r[r] = fmaf(h2[r], dy0, aW3r[r]);
       }
     }
-    f32x16 dz;  // dz2 of tile w
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = fbase + (r & 3) + 8 * (r >> 2);
-      const float* w3 = W3s + f * NO;
-      float acc = 0.0f;
-#pragma unroll
-      for (int o = 0; o < NO; ++o) acc = fmaf(w3[o], dy[o], acc);
-      dz[r] = (h2[r] > 0.0f) ? acc : 0.0f;
-      DZ2T[f * LDT + j] = dz[r];
-      ab2[r] += dz[r];
-      if (!ACTOR) aW3r[r] = fmaf(h2[r], dy[0], aW3r[r]);
-    }
-    if (!ACTOR && w == 0 && h == 0) ab3 += dy[0];
     STAMP(2);
     __syncthreads();  // C
 
@@ -549,48 +643,21 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       }
     }
     if (ACTOR) {
-      // dW3[f][o] += sum_rows h2[f][row] * dy[o][row];  db3
-      // all loads of an 8-row chunk are issued before their first use (one LDS latency per chunk)
-      const float* hrow = H2T + sf * LDT;
+      // gW3^T[o][f = 32w + j] += sum_rows dy[o][row] * h2^T[f][row]   (rows o >= NO of the dy tile are zero)
+      const float* ea = DY + j * LDT + h;                  // dy[o = j][row 2s + h]
+      const float* eb = H2T + (32 * w + j) * LDT + h;      // h2^T[32w + j][row 2s + h]
+      float oa[16], ob[16];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float hv[8], dv[NOH][8];
+      for (int s2 = 0; s2 < 16; ++s2) { oa[s2] = ea[2 * s2]; ob[s2] = eb[2 * s2]; }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hv[q] = hrow[8 * c + q];
-#pragma unroll
-        for (int i = 0; i < NOH; ++i) {
-          const int o = 2 * i + og;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) dv[i][q] = (o < NO) ? DY[o * 32 + 8 * c + q] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < NOH; ++i)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) aW3[i] = fmaf(hv[q], dv[i][q], aW3[i]);
-      }
-      if (tid < NO) {
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float v[16];
-#pragma unroll
-          for (int row = 0; row < 16; ++row) v[row] = DY[tid * 32 + 16 * c + row];
-#pragma unroll
-          for (int row = 0; row < 16; ++row) s += v[row];
-        }
-        ab3 += s;
-      }
+      for (int s2 = 0; s2 < 16; ++s2) gW3 = MFMA32(oa[s2], ob[s2], gW3);
     }
     STAMP(3);
     __syncthreads();  // D': every reader of h2^T is done; the tile is reused for dz1^T
     {
-      // relu'(z1) from the h1^T tile still in LDS (keeps h1 out of the register file across P2-P4)
-      float hm[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hm[r] = H1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        d1[r] = (hm[r] > 0.0f) ? d1[r] : 0.0f;
+        d1[r] = ((relu1 >> r) & 1u) ? d1[r] : 0.0f;
         DZ1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = d1[r];
       }
     }
@@ -631,7 +698,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     __syncthreads();  // E: every exchange tile and the x tile are free
     STAMP(7);
     if (have_next) stage_commit(xr);
-    rin = rnext;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; r_m[q] = n_m[q]; }
     __syncthreads();  // F: next x tile visible
     STAMP(8);
   }
@@ -665,13 +733,29 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
     if (j == 0) slab[oB2 + fbase + (r & 3) + 8 * (r >> 2)] = v;
   }
+  float* red = lds + L.yp;  // epilogue scratch (the tile loop is over)
   if (ACTOR) {
 #pragma unroll
-    for (int i = 0; i < NOH; ++i) {
-      const int o = 2 * i + og;
-      if (o < no) slab[oW3 + sf * no + o] = aW3[i];
+    for (int r = 0; r < 16; ++r) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (o < no) slab[oW3 + (32 * w + j) * no + o] = gW3[r];
     }
-    if (tid < no) slab[oB3 + tid] = ab3;
+    // db3[o]: sum over the lanes of output o (xor tree over the row bits), then over the 4 waves
+    float v = ab3;
+#pragma unroll
+    for (int m = NO; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane < NO) red[w * NO + lane] = v;
+    for (int o = 32; o > 0; o >>= 1) {
+      loss_a += __shfl_down(loss_a, o, 64);
+      loss_b += __shfl_down(loss_b, o, 64);
+    }
+    if (lane == 0) { red[4 * NO + 2 * w] = loss_a; red[4 * NO + 2 * w + 1] = loss_b; }
+    __syncthreads();
+    if (tid < no) slab[oB3 + tid] = ((red[tid] + red[NO + tid]) + red[2 * NO + tid]) + red[3 * NO + tid];
+    if (tid == 0) {
+      slab[P] = ((red[4 * NO] + red[4 * NO + 2]) + red[4 * NO + 4]) + red[4 * NO + 6];
+      slab[P + 1] = ((red[4 * NO + 1] + red[4 * NO + 3]) + red[4 * NO + 5]) + red[4 * NO + 7];
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -684,56 +768,58 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
 #pragma unroll
     for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
     if (tid == 0) slab[oB3] = v;
-  }
-  if (w == 0) {
-    for (int o = 32; o > 0; o >>= 1) {
-      loss_a += __shfl_down(loss_a, o, 64);
-      loss_b += __shfl_down(loss_b, o, 64);
-    }
-    if (lane == 0) {
-      slab[P] = loss_a;
-      slab[P + 1] = loss_b;
+    if (w == 0) {
+      for (int o = 32; o > 0; o >>= 1) loss_a += __shfl_down(loss_a, o, 64);
+      if (lane == 0) {
+        slab[P] = loss_a;
+        slab[P + 1] = 0.0f;
+      }
     }
   }
 }
 
+// 16-byte pieces when every input row is 16-byte aligned and the tile is wide enough for it to matter
 int pick_xv(const float* x, int din) {
   const uintptr_t a = (uintptr_t)x;
-  if (din % 4 == 0 && a % 16 == 0) return 4;
-  if (din % 2 == 0 && a % 8 == 0) return 2;
-  return 1;
+  return (din % 4 == 0 && a % 16 == 0 && din >= 96) ? 4 : 1;
 }
 
-template <int NO, int KT1, bool ACTOR>
+template <int NO, int KT1, bool ACTOR, int XV>
 int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
   const TrainLdsLayout L = make_layout<NO>(KT1);
   const size_t lb = (size_t)L.end * sizeof(float);
   MAVA_ARG_CHECK(lb <= 163840, 8,
                  "ppo_train: %zu bytes of LDS needed (n_out pad %d, input width %d) exceed the 160 KiB of a CU",
                  lb, NO, tk.din);
-  MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR>,
+  MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR, XV>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR>), dim3(n_slab), dim3(256), lb, s, tk, L);
+  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR, XV>), dim3(n_slab), dim3(256), lb, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
+}
+
+template <int NO, int KT1, bool ACTOR>
+int launch_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
+  if (KT1 >= 4 && tk.xv == 4) return launch_train<NO, KT1, ACTOR, (KT1 >= 4 ? 4 : 1)>(tk, n_slab, s);
+  return launch_train<NO, KT1, ACTOR, 1>(tk, n_slab, s);
 }
 
 template <int NO, bool ACTOR>
 int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int kt = tk.din / 32 + 1;  // 32*kt > din: the x tile always has a spare column for the ones (bias) input
 #ifdef MAVA_FAST_BUILD  // developer iteration: only the BASELINE config-2 instantiations
-  if (kt == 3) return launch_train<NO, 3, ACTOR>(tk, n_slab, s);
-  if (kt == 9) return launch_train<NO, 9, ACTOR>(tk, n_slab, s);
+  if (kt == 3) return launch_xv<NO, 3, ACTOR>(tk, n_slab, s);
+  if (kt == 9) return launch_xv<NO, 9, ACTOR>(tk, n_slab, s);
   mava_set_error("fast build: input width %d not instantiated", tk.din);
   return MAVA_EARG(9);
 #else
   switch (kt) {
-    case 1: return launch_train<NO, 1, ACTOR>(tk, n_slab, s);
-    case 2: return launch_train<NO, 2, ACTOR>(tk, n_slab, s);
-    case 3: return launch_train<NO, 3, ACTOR>(tk, n_slab, s);
-    case 4: return launch_train<NO, 4, ACTOR>(tk, n_slab, s);
-    case 5: case 6: return launch_train<NO, 6, ACTOR>(tk, n_slab, s);
-    case 7: case 8: case 9: return launch_train<NO, 9, ACTOR>(tk, n_slab, s);
+    case 1: return launch_xv<NO, 1, ACTOR>(tk, n_slab, s);
+    case 2: return launch_xv<NO, 2, ACTOR>(tk, n_slab, s);
+    case 3: return launch_xv<NO, 3, ACTOR>(tk, n_slab, s);
+    case 4: return launch_xv<NO, 4, ACTOR>(tk, n_slab, s);
+    case 5: case 6: return launch_xv<NO, 6, ACTOR>(tk, n_slab, s);
+    case 7: case 8: case 9: return launch_xv<NO, 9, ACTOR>(tk, n_slab, s);
     default:
       mava_set_error("ppo_train: input width %d > 287 is not instantiated", tk.din);
       return MAVA_EARG(9);

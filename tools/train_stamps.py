@@ -11,7 +11,7 @@ TE, A, O, nA = 128 * 4096, 4, 66, 5
 Rb = TE // 2
 rng = np.random.default_rng(0)
 names = ["P1 layer1", "P2 layer2+head", "P3 loss+dz2", "P4 dh1+sweeps", "P4b dz1 write", "P5a gW2", "P5b gW1", "barrier E",
-         "commit+F", "loop top", "P2a prefetch issue", "P2b mfma loop", "P1a mfma loop", "-", "-", "-"]
+         "commit+F", "loop top", "P2a prefetch issue", "P2b mfma loop", "P1a mfma loop", "barrier A", "x issue", "row issue"]
 # note: with sub-stamps, "P1 layer1" = epilogue after P1a, "P2 layer2+head" = head part after P2b
 l = lib()
 l.mava_debug_set_stamps.argtypes = [C.c_void_p]

@@ -166,11 +166,11 @@ def main() -> None:
                    "parallelism": f"dp{world}"},
     }
 
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json): counters
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_v3_pmc_traffic.json): counters
     # cannot be read from inside this process, so the measured figures of the same workload are attached.
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")) as f:
             traffic = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         pass
@@ -191,7 +191,7 @@ def main() -> None:
         out["roofline"] = {"kernel": "ppo_train_kernel<critic> (fused fwd+loss+bwd+dW)", "bound": "mfma",
                            "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
-                           "traffic": (traffic.get("ppo_train_kernel<1, 9, false>", {}).get("hbm_bytes_uncorrected")
+                           "traffic": (traffic.get("ppo_train_kernel<critic>", {}).get("hbm_bytes_corrected")
                                        if default_shape else None),
                            "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c}
         gae_bytes = 17 * T * E * A + 4 * E * A

@@ -80,7 +80,9 @@ int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x
  * value_broadcast times (value index r*value_broadcast + b).  Sampling: Gumbel-max on
  * Philox4x32-10 keyed by seed with counter (row_offset + row, step, word-group, "POLI").
  * forced_action (rows) i32 or NULL: score these actions instead of sampling.
- * logits (rows, n_actions) or NULL: raw (unmasked) logits out. */
+ * logits (rows, n_actions) or NULL: raw (unmasked) logits out.
+ * rows == 0 or critic_rows == 0 skips that half (its pointers may then be NULL): the learner runs the actor
+ * half on the acting stream and the value half (mava_mlp_forward_f32) on a side stream. */
 int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
                          const float* agents_view, const uint8_t* action_mask,
                          const float* critic_params, int critic_din, const float* critic_input,

@@ -229,7 +229,12 @@ __global__ __launch_bounds__(LPC * NC) void gae_kernel(
 
   const int chunk = threadIdx.x / LPC;
   const int lc = threadIdx.x - chunk * LPC;
-  const long col = ((long)blockIdx.x * LPC + lc) * VEC;
+  // XCD-aware strip order: workgroups go to the 8 XCDs round-robin, so consecutive strips are given to
+  // workgroups of the SAME XCD - neighbouring strips share 64-byte sectors of the done bytes (and, for narrow
+  // strips, 128-byte lines of reward / value), which then hit that XCD's L2 instead of being fetched twice.
+  const int nblk = gridDim.x;
+  const int strip = (nblk % 8 == 0) ? ((int)(blockIdx.x & 7) * (nblk >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+  const long col = ((long)strip * LPC + lc) * VEC;
   const bool live = col < N;
   const long colc = live ? col : 0;
   const bool shifted = last_done != nullptr;

@@ -198,9 +198,13 @@ extern "C" int mava_mlp_forward_f32(const float* params, int din, int n_out, con
   if (blocks > 512) blocks = 512;
 #define LAUNCH_FWD(NO)                                                                        \
   do {                                                                                        \
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<NO>,                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                       (int)lds_bytes<NO>()));                                \
+    static bool attr_set = false;                                                             \
+    if (!attr_set) {                                                                          \
+      MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<NO>,                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                         (int)lds_bytes<NO>()));                              \
+      attr_set = true;                                                                        \
+    }                                                                                         \
     hipLaunchKernelGGL(mlp_forward_kernel<NO>, dim3(blocks), dim3(256), lds_bytes<NO>(), s, tk, \
                        out);                                                                  \
   } while (0)
@@ -227,9 +231,10 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   MAVA_ARG_CHECK(rows >= 0 && critic_rows >= 0 && critic_share >= 1 && value_broadcast >= 1, 1,
                  "mava_policy_step_f32: bad row counts");
   if (rows == 0 && critic_rows == 0) return MAVA_OK;
-  MAVA_ARG_CHECK(actor_params && agents_view && critic_params && critic_input && action &&
-                     log_prob && value,
-                 2, "mava_policy_step_f32: null pointer argument");
+  MAVA_ARG_CHECK(rows == 0 || (actor_params && agents_view && action && log_prob), 2,
+                 "mava_policy_step_f32: null actor pointer argument");
+  MAVA_ARG_CHECK(critic_rows == 0 || (critic_params && critic_input && value), 2,
+                 "mava_policy_step_f32: null critic pointer argument");
   if (g_policy_variant == 2 && actor_din <= 288 && critic_din <= 288) {
     int rc = MAVA_OK;
     if (rows > 0)
@@ -247,15 +252,19 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   int nbc = mava_cdiv(mava_cdiv(critic_rows, 32), 4);
   if (nba > 256) nba = 256;
   if (nbc > 256) nbc = 256;
-  if (nba < 1) nba = 1;
-  if (nbc < 1) nbc = 1;
+  if (nba < 1 && rows > 0) nba = 1;
+  if (nbc < 1 && critic_rows > 0) nbc = 1;
   StepOut so = {action, log_prob, value, logits, forced_action};
   const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
 #define LAUNCH_STEP(NO)                                                                         \
   do {                                                                                          \
     const size_t lb = lds_bytes<NO>() > lds_bytes<1>() ? lds_bytes<NO>() : lds_bytes<1>();      \
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)policy_step_kernel<NO>,                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));   \
+    static bool attr_set = false; /* once per instantiation: the call costs host time on every launch */ \
+    if (!attr_set) {                                                                            \
+      MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)policy_step_kernel<NO>,                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb)); \
+      attr_set = true;                                                                          \
+    }                                                                                           \
     hipLaunchKernelGGL(policy_step_kernel<NO>, dim3(nba + nbc), dim3(256), lb, s, ta, tc, nba,  \
                        action_mask, slo, shi, step, row_offset, value_broadcast, greedy, so);   \
   } while (0)

@@ -54,7 +54,23 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
   const int ntile_n = (N + 31) / 32;
 
   // ---- resident weight slice: wreg[tw][b][s] = W[16b + 2s + h][32*(w + 4tw) + j]
+  // Two passes: every load first (clamped to a valid element, no arithmetic on a loaded value), the zeroing of
+  // the padding afterwards - a conditional load per word makes the compiler wait for memory once per word, which
+  // is what a 16 K-row acting-step launch then spends its time on.
   float wreg[NTW][NB][8];
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw) {
+    const int col = 32 * (w + 4 * tw) + j;
+    const int colc = col < N ? col : (N - 1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int k = 16 * b + 2 * s + h;
+        const int kc = k < K ? k : (K - 1);
+        wreg[tw][b][s] = tk.w[(long)kc * tk.ldw + colc];
+      }
+  }
 #pragma unroll
   for (int tw = 0; tw < NTW; ++tw) {
     const int col = 32 * (w + 4 * tw) + j;
@@ -63,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int k = 16 * b + 2 * s + h;
-        wreg[tw][b][s] = (k < K && col < N) ? tk.w[(long)k * tk.ldw + col] : 0.0f;
+        wreg[tw][b][s] = (k < K && col < N) ? wreg[tw][b][s] : 0.0f;
       }
   }
   if (RM) {

@@ -112,7 +112,7 @@ def mlp_param_count(din: int, n_out: int) -> int:
 
 
 def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, rows: Optional[int] = None,
-                x_share: int = 1) -> torch.Tensor:
+                x_share: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw network outputs (rows, n_out); x is (rows_x, din) and output row r reads x[r // x_share]."""
     _req(params, torch.float32, "params")
     if params.numel() != mlp_param_count(din, n_out):
@@ -124,7 +124,12 @@ def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, row
         rows = x.shape[0] * x_share
     if (rows + x_share - 1) // x_share > x.shape[0]:
         raise ValueError("x has too few rows for rows/x_share")
-    out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, torch.float32, "out")
+        if out.numel() != rows * n_out:
+            raise ValueError(f"out: expected {rows * n_out} elements, got {out.numel()}")
     check(lib().mava_mlp_forward_f32(ptr(params), din, n_out, ptr(x), x_share, rows, ptr(out), stream_ptr()),
           "mava_mlp_forward_f32")
     return out

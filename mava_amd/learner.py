@@ -263,19 +263,27 @@ class FFLearner:
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         idx = None if perm is None else perm[mb * self.Rb : (mb + 1) * self.Rb]
         base = mb * self.Rb
+        # actor: gradient kernels of every replica, fixed-order slab sum into g[:Pa] (+ actor_loss, entropy)
         for u, rep in enumerate(self.reps):
-            acc = u > 0
             av = rep.agents_view[:T].view(TEA, self.Oa)
             ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
             self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA), rep.action.view(TEA),
                         rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA,
                         float(s.clip_eps), float(s.ent_coef), self.slab_a)
+            ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
+        # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
+        # the critic's backward kernels run on this one
+        w_actor = parallel.allreduce_sum_async(self.g[: self.Pa])
+        for u, rep in enumerate(self.reps):
+            av = rep.agents_view[:T].view(TEA, self.Oa)
             cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
             self._timed("critic_grad", ops.ppo_critic_grad, pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA),
                         idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c)
-            ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=acc)
-            ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
-        parallel.allreduce_sum_(self.g)  # RCCL over xGMI; pmean "device" of ff_mappo.py:228-238
+            ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=u > 0)
+        w_rest = parallel.allreduce_sum_async(self.g[self.Pa :])  # critic gradient + the loss scalars
+        for wk in (w_actor, w_rest):
+            if wk is not None:
+                wk.wait()
         self._timed("clip_adam", ops.clip_adam, self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,

@@ -4,10 +4,12 @@ Reference: mava/systems/ppo/ff_mappo.py:224-238 - four `jax.lax.pmean` calls per
 ((grads, loss_info) of actor and critic over the "batch" and "device" axes).  Here every rank owns
 `update_batch_size * num_envs` environments end to end (no data-path collective during rollout,
 GAE, shuffling, forward or backward; advantage normalisation stays local) and
-the only exchange is ONE sum all-reduce per minibatch of the flat buffer
+the only exchange is a sum all-reduce per minibatch of the flat buffer
 [actor grads | critic grads | actor_loss, entropy, value_loss, pad], followed by the 1/(U*D) scale
 inside the fused Adam kernel.  With backend "nccl" this is RCCL over xGMI; at ~307 KB the collective
-is latency-bound, so one flat message (not one per leaf) is the design point.
+is latency-bound, so flat messages (not one per leaf) are the design point: the actor's slice goes out
+as soon as its gradient is reduced and travels while the critic's backward kernel runs, the critic's
+slice and the loss scalars follow, and the Adam kernel waits for both.
 """
 from __future__ import annotations
 
@@ -41,6 +43,15 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def allreduce_sum_async(flat: torch.Tensor):
+    """Start the in-place sum over ranks and return a handle whose .wait() orders the CURRENT stream after the
+    collective (RCCL runs it on its own stream, behind everything already enqueued on the current one), or None
+    on a single rank.  Used to hide the actor's exchange under the critic's backward pass."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:

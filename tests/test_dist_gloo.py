@@ -51,7 +51,15 @@ def _worker(rank, world, port, q):
     _, vl, gc = po.critic_loss_and_grad(loc.pc, A * O, sel(tr["cx"]).reshape(R, -1), sel(tr["value"]).reshape(R),
                                         sel(tr["tgt"]).reshape(R), 0.2, 0.5)
     g = torch.from_numpy(np.concatenate([ga, gc, [la, ent, vl, 0.0]]))
-    parallel.allreduce_sum_(g)
+    g_sync = g.clone()
+    # the learner's exchange: actor slice first (in flight during the critic's backward), then the rest
+    w1 = parallel.allreduce_sum_async(g[: ga.size])
+    w2 = parallel.allreduce_sum_async(g[ga.size :])
+    assert w1 is not None and w2 is not None
+    w1.wait()
+    w2.wait()
+    parallel.allreduce_sum_(g_sync)
+    assert torch.equal(g, g_sync)
     g = g * parallel.grad_scale(update_batch_size=1)
     pb = torch.from_numpy(fa.copy() if rank == 0 else np.zeros_like(fa))
     parallel.broadcast_(pb, src=0)

@@ -258,7 +258,32 @@ class RecLearner:
             rep.action_mask[0].copy_(rep.action_mask[self.T])
             rep.step_count[0].copy_(rep.step_count[self.T])
 
+    def adopt(self, state: RNNLearnerState) -> None:
+        """Make the parameter / optimiser buffers equal to `state` (no-op for trees that already alias them), so
+        that learn() follows its argument like the reference's pure learner_fn - e.g. params restored from a
+        checkpoint (rec_mappo.py:558-566).  Environment and hidden state stay with the learner."""
+        pa = state.params.actor_params["params"]["pre_torso"]["Dense_0"]["kernel"]
+        if not isinstance(pa, torch.Tensor) or pa.data_ptr() != self.p.data_ptr():
+            dev = self.p.device
+            to = lambda tree: self._tree_to(tree, dev)
+            self.actor_network.flat_from_tree(to(state.params.actor_params), self.p[: self.Pa])
+            self.critic_network.flat_from_tree(to(state.params.critic_params), self.p[self.Pa :])
+            for i, (net, sl, st) in enumerate(((self.actor_network, slice(0, self.Pa), state.opt_states.actor_opt_state),
+                                               (self.critic_network, slice(self.Pa, self.P), state.opt_states.critic_opt_state))):
+                net.flat_from_tree(to(st.mu), self.m[sl])
+                net.flat_from_tree(to(st.nu), self.v[sl])
+                self.count[i] = int(torch.as_tensor(st.count).reshape(-1)[0])
+
+    @staticmethod
+    def _tree_to(tree, device):
+        if isinstance(tree, torch.Tensor):
+            return tree.to(device)
+        if isinstance(tree, dict):
+            return {k: RecLearner._tree_to(v, device) for k, v in tree.items()}
+        return tree
+
     def learn(self, learner_state: RNNLearnerState) -> ExperimentOutput:
+        self.adopt(learner_state)
         for n in range(self.n_upd):
             self.update(n)
         U = self.U

@@ -99,6 +99,57 @@ class _RecurrentNet:
         tree.update(self._head_tree(head))
         return {"params": tree}
 
+    def flat_from_tree(self, tree: Dict[str, Any], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Inverse of tree(): gathers a Flax-shaped parameter tree (leading replica dims allowed: replica 0 is
+        taken, like unreplicate_n_dims, mava/utils/jax_utils.py:52-59) into the flat layout the kernels read."""
+        p = tree["params"]
+        cell = p["ScannedRNN_0"]["GRUCell_0"]
+        head = p["action_head"]["Dense_0"] if "action_head" in p else p["Dense_0"]
+
+        def leaf(v, shape):
+            v = torch.as_tensor(v)
+            while v.dim() > len(shape):
+                v = v[0]
+            return v.reshape(shape)
+
+        dev = leaf(p["pre_torso"]["Dense_0"]["kernel"], (self.din, H)).device
+        flat = out if out is not None else torch.empty(self.num_params, dtype=torch.float32, device=dev)
+        self.seg(flat, "Wpre").copy_(leaf(p["pre_torso"]["Dense_0"]["kernel"], (self.din, H)))
+        self.seg(flat, "bpre").copy_(leaf(p["pre_torso"]["Dense_0"]["bias"], (H,)))
+        for g, (ik, hk) in enumerate((("ir", "hr"), ("iz", "hz"), ("in", "hn"))):
+            self.seg(flat, "Wi")[:, g * H : (g + 1) * H].copy_(leaf(cell[ik]["kernel"], (H, H)))
+            self.seg(flat, "bi")[g * H : (g + 1) * H].copy_(leaf(cell[ik]["bias"], (H,)))
+            self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(leaf(cell[hk]["kernel"], (H, H)))
+        self.seg(flat, "bhn").copy_(leaf(cell["hn"]["bias"], (H,)))
+        self.seg(flat, "Wpost").copy_(leaf(p["post_torso"]["Dense_0"]["kernel"], (H, H)))
+        self.seg(flat, "bpost").copy_(leaf(p["post_torso"]["Dense_0"]["bias"], (H,)))
+        self.seg(flat, "Whead").copy_(leaf(head["kernel"], (H, self.n_out)))
+        self.seg(flat, "bhead").copy_(leaf(head["bias"], (self.n_out,)))
+        return flat
+
+    def _apply_sequence(self, params: Any, hstate: torch.Tensor, x: torch.Tensor, done: torch.Tensor):
+        """Shared body of RecurrentActor.apply / RecurrentValueNet.apply: x (T, E, A, din), done (T, E, A),
+        hstate (E, A, 128) -> (new hstate (E, A, 128), outputs (T, E, A, n_out)).  Rows are padded to a multiple
+        of 32 for the tile kernels; off the timed path (evaluator, tests)."""
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        flat = flat.contiguous().float()
+        T, E, A = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        R = E * A
+        Rp = -(-R // 32) * 32
+        dev = x.device
+        xp = torch.zeros((T, Rp, self.din), device=dev)
+        xp[:, :R] = x.reshape(T, R, self.din).float()
+        dp = torch.zeros((T, Rp), dtype=torch.uint8, device=dev)
+        dp[:, :R] = done.reshape(T, R).to(torch.uint8)
+        hp = torch.zeros((Rp, H), device=dev)
+        hp[:R] = hstate.reshape(R, H).float()
+        ws = RecWorkspace(T * Rp, max(self.n_out, 1), dev, training=False)
+        # the padded batch is presented as Rp single-agent "envs", identity permutation
+        y = self.forward_sequence(flat, ws, xp, 1, dp, hp, False, None, T, Rp, Rp, 1, training=False)
+        out = t32_to_rows(y, self.n_out, T * Rp).view(T, Rp, self.n_out)[:, :R].reshape(T, E, A, self.n_out)
+        h_last = t32_to_rows(ws.hs[(T - 1) * Rp * H : T * Rp * H], H, Rp)[:R].reshape(E, A, H)
+        return h_last, out
+
     # ------------------------------------------------------------------------------------- kernels
     def forward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, h0, h0_t32, idx, T, Rm, E, A,
                          training: bool, y_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -185,6 +236,15 @@ class RecurrentActor(_RecurrentNet):
     def _head_tree(self, head):
         return {"action_head": {"Dense_0": head}}
 
+    def apply(self, params: Any, hstate: torch.Tensor, observation_done) -> Tuple[torch.Tensor, Any]:
+        """actor_network.apply(params, hstate, (observation, done)) -> (hstate, distribution) with a leading
+        time axis on observation and done (mava/networks.py:277-294; call site mava/evaluator.py:198-207)."""
+        from .distributions import Categorical
+
+        observation, done = observation_done
+        h, logits = self._apply_sequence(params, hstate, observation.agents_view, done)
+        return h, Categorical(logits, observation.action_mask)
+
 
 class RecurrentValueNet(_RecurrentNet):
     """mava/networks.py:297-331 (head Dense(1) init orthogonal(1.0))."""
@@ -198,6 +258,19 @@ class RecurrentValueNet(_RecurrentNet):
 
     def _head_tree(self, head):
         return {"Dense_0": head}
+
+    def apply(self, params: Any, hstate: torch.Tensor, observation_done) -> Tuple[torch.Tensor, torch.Tensor]:
+        """critic_network.apply(params, hstate, (observation, done)) -> (hstate, value (T, E, A))
+        (mava/networks.py:306-331)."""
+        observation, done = observation_done
+        if self.centralised_critic:
+            if not hasattr(observation, "global_state") or observation.global_state is None:
+                raise ValueError("Global state must be provided to the centralised critic.")  # networks.py:196-197 analogue
+            x = observation.global_state
+        else:
+            x = observation.agents_view
+        h, v = self._apply_sequence(params, hstate, x, done)
+        return h, v.squeeze(-1)
 
 
 def t32_to_rows(src: torch.Tensor, N: int, rows: int) -> torch.Tensor:

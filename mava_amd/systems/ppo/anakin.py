@@ -1,8 +1,8 @@
 """Experiment driver shared by the four PPO systems: the host loop of
 mava/systems/ppo/ff_mappo.py:435-553 (run_experiment) - train for num_updates_per_eval updates,
 synchronise, report steps_per_second with the reference's own accounting, evaluate, repeat.
-Logging is reduced to the metric names of SURVEY.md §5.5 on stdout/JSON; checkpointing uses
-mava_amd/utils/checkpointing.py.
+Logging is reduced to the metric names of SURVEY.md §5.5 on stdout/JSON (mava_amd/utils/logger.py holds the
+MavaLogger / marl-eval JSON writer); checkpointing uses mava_amd/utils/checkpointing.py.
 """
 from __future__ import annotations
 
@@ -15,6 +15,31 @@ import torch
 
 from ...config import Config, check_total_timesteps
 from ...learner import get_final_step_metrics
+
+
+def _unreplicate_n_dims(tree: Any, n: int = 2) -> Any:
+    """mava/utils/jax_utils.py:52-59: x[0, 0] on every array leaf with at least n leading dims."""
+    if isinstance(tree, torch.Tensor):
+        return tree[(0,) * n] if tree.dim() >= n else tree
+    if hasattr(tree, "_asdict"):
+        return type(tree)(**{k: _unreplicate_n_dims(v, n) for k, v in tree._asdict().items()})
+    if isinstance(tree, dict):
+        return {k: _unreplicate_n_dims(v, n) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_unreplicate_n_dims(v, n) for v in tree)
+    return tree
+
+
+def _tree_to(tree: Any, device) -> Any:
+    if isinstance(tree, torch.Tensor):
+        return tree.to(device)
+    if hasattr(tree, "_asdict"):
+        return type(tree)(**{k: _tree_to(v, device) for k, v in tree._asdict().items()})
+    if isinstance(tree, dict):
+        return {k: _tree_to(v, device) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_tree_to(v, device) for v in tree)
+    return tree
 
 
 def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable, add_global_state: bool,
@@ -39,12 +64,32 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
 
     learn, actor_network, learner_state = learner_setup(env, (key, actor_key, critic_key), config)
 
-    from ...evaluator import get_eval_fn, make_ff_eval_act_fn
+    from ...evaluator import get_eval_fn, make_ff_eval_act_fn, make_rec_eval_act_fn
 
-    # The evaluator runs the feed-forward act function; the recurrent act function (evaluator.py:189-207) is
-    # not built yet, so recurrent systems skip evaluation and report training metrics only.
-    evaluator = None if recurrent else get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, config), config,
-                                                   absolute_metric=False)
+    # evaluator.py:175-207: feed-forward or recurrent act function over actor_network.apply
+    if recurrent:
+        act_fn = make_rec_eval_act_fn(actor_network.apply, config)
+        init_act_state = {"hidden_state": torch.zeros((eval_env.num_envs, eval_env.num_agents, 128), device=eval_env.device)}
+    else:
+        act_fn, init_act_state = make_ff_eval_act_fn(actor_network.apply, config), None
+    evaluator = get_eval_fn(eval_env, act_fn, config, absolute_metric=False)
+
+    # checkpointing (ff_mappo.py:440-459 load, :520-531 save)
+    ck = config.logger.checkpointing
+    checkpointer = None
+    if bool(ck.save_model) and rank == 0:
+        from ...utils.checkpointing import Checkpointer
+
+        checkpointer = Checkpointer(metadata=config.to_container() if hasattr(config, "to_container") else None,
+                                    model_name=str(config.logger.system_name),
+                                    **{k: (v if v != "" else None) for k, v in dict(ck.save_args).items()})
+    if bool(ck.load_model):
+        from ...utils.checkpointing import Checkpointer
+
+        loaded = Checkpointer(model_name=str(config.logger.system_name), **{k: v for k, v in dict(ck.load_args).items()})
+        restored_params, _ = loaded.restore_params(input_params=learner_state.params)
+        restored_params = _tree_to(restored_params, eval_env.device)  # checkpoints hold host tensors
+        learner_state = learner_state._replace(params=restored_params)  # learn() adopts trees that do not alias its buffers
 
     def emit(rec: Dict[str, Any]) -> None:
         if rank == 0:
@@ -66,13 +111,14 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
         for k, v in out.train_metrics.items():
             rec[k] = float(v.float().mean())  # TRAIN metrics are mean-reduced (mava/utils/logger.py:72-74)
         # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:513 vs :535)
-        if evaluator is not None:
-            trained_params = learner_state.params.actor_params
-            eval_metrics = evaluator(trained_params, key_e + eval_step)
-            eval_return = float(eval_metrics["episode_return"].float().mean())
-            rec["eval_episode_return"] = eval_return
-        else:
-            eval_return = rec.get("episode_return", 0.0)
+        trained_params = learner_state.params.actor_params
+        eval_metrics = evaluator(trained_params, key_e + eval_step, init_act_state)
+        eval_return = float(eval_metrics["episode_return"].float().mean())
+        rec["eval_episode_return"] = eval_return
         emit(rec)
         learner_state = out.learner_state
+        if checkpointer is not None:
+            # unreplicate_n_dims (jax_utils.py:52-59): drop the (device, update_batch) leading dims of the leaves
+            unrep = _unreplicate_n_dims(learner_state)
+            checkpointer.save(timestep=t, unreplicated_learner_state=unrep, episode_return=eval_return)
     return eval_return

@@ -143,3 +143,43 @@ def test_learn_contract_shapes(dev):
     ev = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
     m = ev(out.learner_state.params.actor_params, 0)
     assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes
+
+
+@pytest.mark.parametrize("system", ["ff_mappo", "rec_mappo"])
+def test_run_experiment_with_eval_and_checkpoint(dev, system, tmp_path, monkeypatch):
+    """The host loop of ff_mappo.py:435-553 / rec_mappo.py:579-713 on the synthetic env: train, evaluate through the
+    (feed-forward / recurrent) act function, save a checkpoint, and start a second run from it."""
+    import importlib
+
+    from mava_amd.config import compose
+    from mava_amd.utils.checkpointing import Checkpointer
+
+    monkeypatch.chdir(tmp_path)
+    mod = importlib.import_module(f"mava_amd.systems.ppo.{system}")
+    cfg = compose(f"default_{system}", ["env/scenario=tiny-2ag", "arch.num_envs=32", "system.rollout_length=8",
+                                        "system.update_batch_size=1", "system.num_updates=4", "arch.num_evaluation=2",
+                                        "arch.num_eval_episodes=16", "system.num_minibatches=2", "system.ppo_epochs=1"])
+    cfg.env.kwargs.time_limit = 12  # short evaluation episodes
+    cfg.logger.checkpointing.save_model = True
+    cfg.logger.checkpointing.save_args.checkpoint_uid = "t"
+    recs = []
+    mod.run_experiment(cfg, log=recs.append)
+    assert len(recs) == 2 and recs[1]["timestep"] == 2 * recs[0]["timestep"]
+    for r in recs:
+        assert r["steps_per_second"] > 0 and np.isfinite(r["total_loss"]) and np.isfinite(r["eval_episode_return"])
+    ck = Checkpointer(model_name=system, checkpoint_uid="t")
+    assert ck.latest_step() is not None
+    raw = ck.restore_learner_state_raw()
+    assert "params" in raw and raw["params"]["actor_params"]["params"]
+    first_kernel = next(iter(next(iter(raw["params"]["actor_params"]["params"].values())).values()))["kernel"]
+    assert first_kernel.dim() == 2  # unreplicated: no (device, update_batch) leading dims
+
+    cfg2 = compose(f"default_{system}", ["env/scenario=tiny-2ag", "arch.num_envs=32", "system.rollout_length=8",
+                                         "system.update_batch_size=1", "system.num_updates=2", "arch.num_evaluation=1",
+                                         "arch.num_eval_episodes=16", "system.num_minibatches=2", "system.ppo_epochs=1"])
+    cfg2.env.kwargs.time_limit = 12
+    cfg2.logger.checkpointing.load_model = True
+    cfg2.logger.checkpointing.load_args.checkpoint_uid = "t"
+    recs2 = []
+    mod.run_experiment(cfg2, log=recs2.append)
+    assert len(recs2) == 1 and np.isfinite(recs2[0]["total_loss"])

@@ -283,3 +283,84 @@ def test_rec_dense_rejects_unsupported_t32_width(dev):
     with pytest.raises(MavaHipError):
         check(lib().mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, 155, 0, ptr(w), 128, None, None, ptr(y), 155, 128, 32, 0,
                                        stream_ptr()), "dense")
+
+
+def test_recurrent_apply_and_eval_act_fn(dev):
+    """actor_network.apply(params, hstate, (obs[None], done[None])) -> (hstate, dist) and the evaluator's recurrent
+    act function (mava/evaluator.py:189-207) against the oracle, stepping a hidden state over several calls; the row
+    count (E*A = 20) is not a multiple of the kernels' 32-row tile."""
+    from types import SimpleNamespace
+
+    from mava_amd.evaluator import make_rec_eval_act_fn
+    from mava_amd.networks import DiscreteActionHead, MLPTorso
+    from mava_amd.rec_networks import RecurrentActor, RecurrentValueNet
+    from mava_amd.types import Observation, ObservationGlobalState, TimeStep
+
+    rng = np.random.default_rng(5)
+    E, A, din, nA, steps = 5, 4, 23, 7, 4
+    actor = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
+    flat = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
+    tree = actor.tree(_t(flat, dev), (1, 1))  # Flax-shaped, with (device, update_batch) leading dims
+    assert torch.equal(actor.flat_from_tree(tree).cpu(), torch.from_numpy(flat))
+    config = SimpleNamespace(arch=SimpleNamespace(evaluation_greedy=True))
+    act = make_rec_eval_act_fn(actor.apply, config)
+    h_or = np.zeros((E * A, 128))
+    state = {"hidden_state": torch.zeros((E, A, 128), device=dev)}
+    for k in range(steps):
+        av = rng.standard_normal((E, A, din)).astype(np.float32)
+        mask = rng.random((E, A, nA)) > 0.3
+        mask[..., 0] = True
+        last = rng.random(E) < 0.4
+        ts = TimeStep(_t(np.where(last, 2, 1).astype(np.int8), dev), None, None,
+                      Observation(_t(av, dev), _t(mask, dev), torch.zeros((E, A), dtype=torch.int32, device=dev)), {})
+        action, state = act(tree, ts, None, state)
+        done = np.repeat(last[:, None], A, 1).reshape(1, E * A)
+        want, _, h_or = ro.rec_forward(flat, din, nA, av.reshape(1, E * A, din), done, h_or)
+        logits = np.where(mask.reshape(E * A, nA), want[0], np.finfo(np.float32).min)
+        assert action.shape == (E, A)
+        # greedy action = argmax of the masked logits (ties are measure-zero for random inputs)
+        assert np.array_equal(action.cpu().numpy().reshape(-1), logits.argmax(-1))
+        assert_close(state["hidden_state"].cpu().numpy().reshape(E * A, 128), h_or, 1e-5, "eval hidden state")
+
+    # critic: centralised input, value shape (T, E, A), error without a global state
+    S = 31
+    critic = RecurrentValueNet(MLPTorso([128]), MLPTorso([128]), True, S)
+    fc = ro.init_rec(rng, S, 1, 1.0).astype(np.float32)
+    gs = rng.standard_normal((2, E, A, S)).astype(np.float32)
+    dn = rng.random((2, E, A)) < 0.3
+    h0 = rng.standard_normal((E, A, 128)).astype(np.float32)
+    obs = ObservationGlobalState(torch.zeros((2, E, A, din), device=dev), None, _t(gs, dev), None)
+    h1, v = critic.apply(_t(fc, dev), _t(h0, dev), (obs, _t(dn, dev)))
+    want, _, h_last = ro.rec_forward(fc, S, 1, gs.reshape(2, E * A, S), dn.reshape(2, E * A), h0.reshape(E * A, 128))
+    assert v.shape == (2, E, A)
+    assert_close(v.cpu().numpy().reshape(2, E * A), want[..., 0], 1e-5, "recurrent value")
+    assert_close(h1.cpu().numpy().reshape(E * A, 128), h_last, 1e-5, "critic hidden state")
+    with pytest.raises(ValueError):
+        critic.apply(_t(fc, dev), _t(h0, dev), (Observation(torch.zeros((2, E, A, din), device=dev), None, None), _t(dn, dev)))
+
+
+def test_rec_learner_adopts_foreign_params(dev):
+    """learn(state) must follow its argument: parameter trees that do not alias the learner's buffers (e.g. restored
+    from a checkpoint, rec_mappo.py:558-566) are copied in; the learner's own trees are a no-op."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_mappo
+    from mava_amd.types import Params
+
+    cfg = compose("default_rec_mappo", ["env/scenario=tiny-2ag", "arch.num_envs=32", "system.rollout_length=4",
+                                       "system.update_batch_size=1", "system.num_minibatches=2", "system.ppo_epochs=1"])
+    cfg.system.num_updates_per_eval = 1
+    env, _ = envs.make(cfg, add_global_state=True)
+    learn, actor_network, state = rec_mappo.learner_setup(env, (1, 2, 3), cfg)
+    L = learn.learner
+    before = L.p.clone()
+    L.adopt(state)
+    assert torch.equal(L.p, before)
+    g = torch.Generator().manual_seed(0)
+    fa = torch.randn(L.Pa, generator=g)
+    fc = torch.randn(L.P - L.Pa, generator=g)
+    foreign = Params(L.actor_network.tree(fa), L.critic_network.tree(fc))  # host tensors, no replica dims
+    L.adopt(state._replace(params=foreign))
+    assert torch.equal(L.p[: L.Pa].cpu(), fa) and torch.equal(L.p[L.Pa :].cpu(), fc)
+    assert torch.equal(state.params.actor_params["params"]["pre_torso"]["Dense_0"]["kernel"][0, 0].cpu(),
+                       fa[: L.Oa * 128].view(L.Oa, 128))  # the state's trees are views of the adopted buffers

@@ -83,25 +83,30 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
       }
   }
   if (RM) {
-    for (int i = tid; i < 32 * ldx; i += 256) lds[i] = 0.0f;
+    for (int i = tid; i < 32 * ldx + 4; i += 256) lds[i] = 0.0f;
     __syncthreads();
   }
 
   const int ntiles = tk.rows / 32;
+  // element (it, f, j) of the T32 output sits at ((it*N + f)*32 + j): one per-lane base per (tile, n-tile), the 16
+  // accumulator registers at compile-time offsets from it (no 64-bit address per element)
+#define DOFF(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
   auto epilogue = [&](int it, f32x16 (&acc)[NTW]) {
     // activation, optional relu-mask gate, coalesced T32 store
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
+      const long base = ((long)it * N + fb) * 32 + j;
+      float* const yo = tk.y + base;
+      const float* const go = tk.gate != nullptr ? tk.gate + base : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = fb + (r & 3) + 8 * (r >> 2);
         if (f < N) {
           float v = acc[tw][r];
           if (tk.relu) v = fmaxf(v, 0.0f);
-          const long o = ((long)it * N + f) * 32 + j;
-          if (tk.gate != nullptr) v = (tk.gate[o] > 0.0f) ? v : 0.0f;
-          tk.y[o] = v;
+          if (go != nullptr) v = (go[DOFF(r)] > 0.0f) ? v : 0.0f;
+          yo[DOFF(r)] = v;
         }
       }
     }
@@ -110,30 +115,45 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
+      const float* const yo = tk.y + ((long)it * N + fb) * 32 + j;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = fb + (r & 3) + 8 * (r >> 2);
         float a0 = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
-        if (tk.accumulate && f < N) a0 += tk.y[((long)it * N + f) * 32 + j];
+        if (tk.accumulate && f < N) a0 += yo[DOFF(r)];
         acc[tw][r] = a0;
       }
     }
   };
 
   if (RM) {
-    // ---- row-major source: gather 32 rows into LDS, B operands one batch ahead
-    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
-      __syncthreads();  // previous tile's readers done
-      const int srow = tid >> 3, l8 = tid & 7;
-      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld + l8;
-      float* xs = lds + srow * ldx + l8;
-      const int nfull = K >> 3;
+    // ---- row-major source: the next tile's 32 gathered rows travel global -> registers during this tile's MFMAs
+    // and are written to the LDS tile after its last reader (branch-free single path: a piece past the row end
+    // is loaded from the row start and stored to a dummy slot); B operands are read one batch ahead.
+    const int srow = tid >> 3, l8 = tid & 7;
+    float* const xs = lds + srow * ldx;
+    float* const dummy = lds + 32 * ldx;
+    float xr[2 * NB];
+    auto issue = [&](int it) {
+      const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld;
 #pragma unroll
       for (int i = 0; i < 2 * NB; ++i) {
-        if (i < nfull) xs[8 * i] = xrow[8 * i];
-        else if (i == nfull && l8 + 8 * i < K) xs[8 * i] = xrow[8 * i];
+        const int c = l8 + 8 * i;
+        xr[i] = xrow[c < K ? c : 0];
+      }
+    };
+    int it = blockIdx.x;
+    if (it < ntiles) issue(it);
+    for (; it < ntiles; it += gridDim.x) {
+      __syncthreads();  // previous tile's readers done
+#pragma unroll
+      for (int i = 0; i < 2 * NB; ++i) {
+        const int c = l8 + 8 * i;
+        float* q = c < K ? xs + c : dummy;
+        *q = xr[i];
       }
       __syncthreads();
+      if (it + (int)gridDim.x < ntiles) issue(it + gridDim.x);  // in flight during the MFMAs below
       const float* xb = lds + j * ldx + h;  // x[row j][k + h], zero padded
       f32x16 acc[NTW];
       init_acc(it, acc);
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
 
 template <int NB, int NTW, bool RM, bool FULLK>
 int launch_dense_rm(const DenseTask& tk, hipStream_t s) {
-  const size_t lb = RM ? (size_t)32 * (16 * NB + 1) * sizeof(float) : 0;
+  const size_t lb = RM ? ((size_t)32 * (16 * NB + 1) + 4) * sizeof(float) : 0;
   if (lb > 0)
     MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_kernel<NB, NTW, RM, FULLK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));

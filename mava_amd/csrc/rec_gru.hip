@@ -44,7 +44,11 @@ __device__ __forceinline__ long ext_row(const ScanTask& tk, int t, int m) {
   return ((long)t * tk.E + env) * tk.A + a;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the scan's
+// elementwise phase runs with the MFMA pipe idle (one wave per SIMD), and libm's expf / tanhf / IEEE division cost
+// ~8 K of the ~27 K cycles a time step took.  tanh(x) = 1 - 2 / (exp(2x) + 1) saturates correctly at both ends.
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
   __shared__ float HT[MLP_H * LDT];
@@ -82,14 +86,15 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
 
   // gate pre-activations of the CURRENT step (loaded one step ahead, under the previous step's MFMAs)
   float gr[16], gz[16], gin[16];
+  const int lane_off = fb * 32 + j;  // element (feature fb, row j) of a T32 tile; the rest are immediates
+#define OFFW(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
   auto load_gi = [&](int t) {
-    const float* git = tk.gi + ((long)t * tiles_per_t + mt) * G3 * 32;
+    const float* git = tk.gi + ((long)t * tiles_per_t + mt) * G3 * 32 + lane_off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int f = fb + (r & 3) + 8 * (r >> 2);
-      gr[r] = git[(long)f * 32 + j];
-      gz[r] = git[(long)(MLP_H + f) * 32 + j];
-      gin[r] = git[(long)(2 * MLP_H + f) * 32 + j];
+      gr[r] = git[OFFW(r)];
+      gz[r] = git[MLP_H * 32 + OFFW(r)];
+      gin[r] = git[2 * MLP_H * 32 + OFFW(r)];
     }
   };
   load_gi(0);
@@ -125,21 +130,22 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
     float hn[16], hp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hp[r] = HT[(fb + (r & 3) + 8 * (r >> 2)) * LDT + j];
+    float* const hs_o = tk.hs + tile * (MLP_H * 32) + lane_off;
+    float* const hp_o = tk.hprev ? tk.hprev + tile * (MLP_H * 32) + lane_off : nullptr;
+    float* const sv = tk.saved ? tk.saved + tile * (4 * MLP_H) * 32 + lane_off : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int f = fb + (r & 3) + 8 * (r >> 2);
       const float rr = sigmoidf_(ar[r]);
       const float zz = sigmoidf_(az[r]);
-      const float nn = tanhf(gn[r] + rr * an[r]);
+      const float nn = tanhf_(gn[r] + rr * an[r]);
       hn[r] = (1.0f - zz) * nn + zz * hp[r];
-      tk.hs[(tile * MLP_H + f) * 32 + j] = hn[r];
-      if (tk.hprev != nullptr) tk.hprev[(tile * MLP_H + f) * 32 + j] = hp[r];
-      if (tk.saved != nullptr) {
-        float* sv = tk.saved + tile * (4 * MLP_H) * 32;
-        sv[(long)f * 32 + j] = rr;
-        sv[(long)(MLP_H + f) * 32 + j] = zz;
-        sv[(long)(2 * MLP_H + f) * 32 + j] = nn;
-        sv[(long)(3 * MLP_H + f) * 32 + j] = an[r];
+      hs_o[OFFW(r)] = hn[r];
+      if (hp_o != nullptr) hp_o[OFFW(r)] = hp[r];
+      if (sv != nullptr) {
+        sv[OFFW(r)] = rr;
+        sv[MLP_H * 32 + OFFW(r)] = zz;
+        sv[2 * MLP_H * 32 + OFFW(r)] = nn;
+        sv[3 * MLP_H * 32 + OFFW(r)] = an[r];
       }
     }
     __syncthreads();  // every wave has read HT
@@ -168,18 +174,25 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
 
   // per-step inputs of the CURRENT step, loaded one step ahead (under the previous step's 192 MFMAs)
   float i_r[16], i_z[16], i_n[16], i_hl[16], i_hp[16], i_dh[16];
+  // One per-lane base pointer per array and step, every element at a COMPILE-TIME offset from it
+  // (OFF(r) floats, < 4 KiB: an instruction immediate).  Written as sv[(long)f * 32 + j] the sign extension of
+  // f = fb + const does not distribute, the compiler forms one 64-bit address per element, hoists the ~150
+  // loop-invariant halves out of the time loop and spills them (scratch traffic shares vmcnt with the prefetch).
+#define OFF(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
+  const int lane_off = fb * 32 + j;
   auto load_step = [&](int t) {
     const long tile = (long)t * tiles_per_t + mt;
-    const float* sv = tk.saved + tile * (4 * MLP_H) * 32;
+    const float* sv = tk.saved + tile * (4 * MLP_H) * 32 + lane_off;
+    const float* hpv = tk.hprev + tile * (MLP_H * 32) + lane_off;
+    const float* dho = tk.dh_out + tile * (MLP_H * 32) + lane_off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int f = fb + (r & 3) + 8 * (r >> 2);
-      i_r[r] = sv[(long)f * 32 + j];
-      i_z[r] = sv[(long)(MLP_H + f) * 32 + j];
-      i_n[r] = sv[(long)(2 * MLP_H + f) * 32 + j];
-      i_hl[r] = sv[(long)(3 * MLP_H + f) * 32 + j];
-      i_hp[r] = tk.hprev[(tile * MLP_H + f) * 32 + j];
-      i_dh[r] = tk.dh_out[(tile * MLP_H + f) * 32 + j];
+      i_r[r] = sv[OFF(r)];
+      i_z[r] = sv[MLP_H * 32 + OFF(r)];
+      i_n[r] = sv[2 * MLP_H * 32 + OFF(r)];
+      i_hl[r] = sv[3 * MLP_H * 32 + OFF(r)];
+      i_hp[r] = hpv[OFF(r)];
+      i_dh[r] = dho[OFF(r)];
     }
   };
   load_step(tk.T - 1);
@@ -187,9 +200,13 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
     const long tile = (long)t * tiles_per_t + mt;
     const bool rs = tk.done[ext_row(tk, t, m)] != 0;
     float dhp[16];
+    float* const gi_o = tk.dgi + tile * G3 * 32 + lane_off;
+    float* const gh_o = tk.dgh + tile * G3 * 32 + lane_off;
+    float* const dgl = DG + fb * LDT + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int f = fb + (r & 3) + 8 * (r >> 2);
+      constexpr int LOFF = 0;  // (LDS offsets are 32-bit: no hoisting problem)
+      const int fo = ((r & 3) + 8 * (r >> 2)) * LDT + LOFF;
       const float rr = i_r[r], zz = i_z[r], nn = i_n[r], hl = i_hl[r], hp = i_hp[r];
       const float dh = i_dh[r] + dhc[r];
       const float dn = dh * (1.0f - zz);
@@ -200,17 +217,18 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
       const float dghn = dn_pre * rr;
       const float dz_pre = dz * zz * (1.0f - zz);
       const float dr_pre = dr * rr * (1.0f - rr);
-      float* gi_o = tk.dgi + tile * G3 * 32;
-      float* gh_o = tk.dgh + tile * G3 * 32;
-      gi_o[(long)f * 32 + j] = dr_pre;
-      gi_o[(long)(MLP_H + f) * 32 + j] = dz_pre;
-      gi_o[(long)(2 * MLP_H + f) * 32 + j] = dn_pre;
-      gh_o[(long)f * 32 + j] = dr_pre;
-      gh_o[(long)(MLP_H + f) * 32 + j] = dz_pre;
-      gh_o[(long)(2 * MLP_H + f) * 32 + j] = dghn;
-      DG[f * LDT + j] = dr_pre;
-      DG[(MLP_H + f) * LDT + j] = dz_pre;
-      DG[(2 * MLP_H + f) * LDT + j] = dghn;
+      gi_o[OFF(r)] = dr_pre;
+      gi_o[MLP_H * 32 + OFF(r)] = dz_pre;
+      gi_o[2 * MLP_H * 32 + OFF(r)] = dn_pre;
+      gh_o[OFF(r)] = dr_pre;
+      gh_o[MLP_H * 32 + OFF(r)] = dz_pre;
+      gh_o[2 * MLP_H * 32 + OFF(r)] = dghn;
+      dgl[fo] = dr_pre;
+      dgl[MLP_H * LDT + fo] = dz_pre;
+      dgl[2 * MLP_H * LDT + fo] = dghn;
+      // keep each feature's nine stores next to its arithmetic: clustered, the 96 results are all live at once
+      // on top of 192 resident weight words and the 96-word prefetch, and spill (scratch shares vmcnt with the prefetch)
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t > 0) load_step(t - 1);  // in flight during the MFMAs below
     __syncthreads();

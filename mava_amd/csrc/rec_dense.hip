@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
   // element (it, f, j) of the T32 output sits at ((it*N + f)*32 + j): one per-lane base per (tile, n-tile), the 16
   // accumulator registers at compile-time offsets from it (no 64-bit address per element)
 #define DOFF(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
-  auto epilogue = [&](int it, f32x16 (&acc)[NTW]) {
+  // gate values of n-tile 0 can be handed in already loaded (gpre, prefetched a tile or more ahead)
+  auto epilogue = [&](int it, f32x16 (&acc)[NTW], const float (&gpre)[16], bool use_pre) {
     // activation, optional relu-mask gate, coalesced T32 store
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
@@ -105,11 +106,21 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
         if (f < N) {
           float v = acc[tw][r];
           if (tk.relu) v = fmaxf(v, 0.0f);
-          if (go != nullptr) v = (go[DOFF(r)] > 0.0f) ? v : 0.0f;
+          if (go != nullptr) {
+            const float gv = (use_pre && tw == 0) ? gpre[r] : go[DOFF(r)];
+            v = (gv > 0.0f) ? v : 0.0f;
+          }
           yo[DOFF(r)] = v;
         }
       }
     }
+  };
+  // raw gate loads of n-tile 0 for tile `it` (features past N clamp to the tile's first feature)
+  auto load_gate = [&](int it, float (&g)[16]) {
+    const int fb = 32 * w + 4 * h;
+    const float* const go = tk.gate + ((long)it * N + fb) * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = go[(fb + (r & 3) + 8 * (r >> 2) < N) ? DOFF(r) : 0];
   };
   auto init_acc = [&](int it, f32x16 (&acc)[NTW]) {
 #pragma unroll
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
     float* const xs = lds + srow * ldx;
     float* const dummy = lds + 32 * ldx;
     float xr[2 * NB];
+    const float gnone[16] = {};
     auto issue = [&](int it) {
       const float* xrow = tk.x + gather_row(tk, it * 32 + srow) * tk.x_ld;
 #pragma unroll
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      epilogue(it, acc);
+      epilogue(it, acc, gnone, false);
     }
   } else {
     // ---- T32 source: B operands stream straight from memory through a ring of RDX batches that runs
@@ -201,21 +213,73 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
         }
       }
     };
+    const bool pf_gate = (NTW == 1) && tk.gate != nullptr && (32 * w < N);
+    if (NB <= 2) {
+      // Narrow inputs (the n_out-wide dlogits of the head backward): a tile is only NB*8 MFMAs, far shorter than a
+      // memory round trip, so the whole x tile AND the gate values run PF tiles ahead through rotating registers.
+      constexpr int PF = 3;
+      float xq[PF + 1][NB][8], gq[PF + 1][16];
+      int it = blockIdx.x;
+#pragma unroll
+      for (int d = 1; d <= PF; ++d) {
+        const int itd = it + (d - 1) * (int)gridDim.x;
+        const int itc = itd < ntiles ? itd : (ntiles - 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) load_batch(tile_ptr(itc), b, xq[d][b]);
+        if (pf_gate) load_gate(itc, gq[d]);
+      }
+      for (; it < ntiles; it += gridDim.x) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {  // rotate: slot 0 = this tile
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) xq[d][b][s] = xq[d + 1][b][s];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gq[d][r] = gq[d + 1][r];
+        }
+        {
+          const int itd = it + PF * (int)gridDim.x;
+          const int itc = itd < ntiles ? itd : (ntiles - 1);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) load_batch(tile_ptr(itc), b, xq[PF][b]);
+          if (pf_gate) load_gate(itc, gq[PF]);
+        }
+        f32x16 acc[NTW];
+        init_acc(it, acc);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int tw = 0; tw < NTW; ++tw) {
+            if (w + 4 * tw < ntile_n) {
+#pragma unroll
+              for (int s = 0; s < 8; ++s) acc[tw] = MFMA32(wreg[tw][b][s], xq[0][b][s], acc[tw]);
+            }
+          }
+        epilogue(it, acc, gq[0], pf_gate);
+      }
+      return;
+    }
     float xo[RDX][8];
+    float gcur[16], gnext[16];
     int it = blockIdx.x;
     const float* xt_cur = tile_ptr(it < ntiles ? it : 0);
 #pragma unroll
     for (int d = 0; d < PD; ++d) load_batch(xt_cur, d % NB, xo[d]);  // PD <= NB - 1 always (RDX divides NB)
+    if (pf_gate && it < ntiles) load_gate(it, gnext);
     for (; it < ntiles; it += gridDim.x) {
       const int itn = it + gridDim.x;
       const float* xt_next = (itn < ntiles) ? tile_ptr(itn) : xt_cur;
+      if (pf_gate) {  // this tile's gate values arrived during the previous tile; the next tile's go out now
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gcur[r] = gnext[r];
+        load_gate(itn < ntiles ? itn : it, gnext);
+      }
       f32x16 acc[NTW];
       init_acc(it, acc);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int bq = b + PD;
           if (bq < NB) load_batch(xt_cur, bq, xo[bq % RDX]);
           else load_batch(xt_next, bq - NB, xo[bq % RDX]);
@@ -229,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      epilogue(it, acc);
+      epilogue(it, acc, gcur, pf_gate);
       xt_cur = xt_next;
     }
   }

@@ -73,6 +73,8 @@ def main() -> None:
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-critic-aggregation", action="store_true",
+                    help="centralised critic: one network pass per AGENT row (the reference's A identical passes) instead of one per (t,e) row")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +123,10 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.no_critic_aggregation:
+        from mava_amd._lib import lib as _mava_lib
+
+        _mava_lib().mava_ppo_set_critic_aggregation(0)
     log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc}")
     for i in range(args.warmup):
         L.update(0)
@@ -181,28 +187,39 @@ def main() -> None:
         timers = {k: _ev_ms(v) for k, v in L.timers.items()}
         avg = {k: sum(v) / len(v) for k, v in timers.items() if v}
         rows = L.Rb * A  # agent rows per minibatch launch
-        # algorithmic FLOPs per agent-row (2*MAC; bwd = 2*fwd - first-layer dX)
+        # With a centralised critic on a shared global state (x_share == A) the critic kernel evaluates each (t,e)
+        # row once and back-propagates the sum of its agents' loss gradients (mava_ppo_set_critic_aggregation,
+        # default on): its EXECUTED matrix work is 1/A of the reference's A identical passes.  Rooflines are
+        # priced on executed FLOPs.
+        aggregated = bool(getattr(L, "critic_share", 1) == A and 1 < A <= 8 and not args.no_critic_aggregation)
+        rows_c = L.Rb if aggregated else rows
+        # algorithmic FLOPs per row (2*MAC; bwd = 2*fwd - first-layer dX)
         fwd_c = 2 * (L.Oc * 128 + 128 * 128 + 128)
-        flop_c = (3 * fwd_c - 2 * L.Oc * 128) * rows
+        flop_c = (3 * fwd_c - 2 * L.Oc * 128) * rows_c
         fwd_a = 2 * (L.Oa * 128 + 128 * 128 + 128 * L.nA)
         flop_a = (3 * fwd_a - 2 * L.Oa * 128) * rows
         tf_c = flop_c / (avg["critic_grad"] * 1e-3) / 1e12
         tf_a = flop_a / (avg["actor_grad"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "ppo_train_kernel<critic> (fused fwd+loss+bwd+dW)", "bound": "mfma",
-                           "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
-                           "traffic": (traffic.get("ppo_train_kernel<critic>", {}).get("hbm_bytes_corrected")
-                                       if default_shape else None),
-                           "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c}
+        roof_c = {"kernel": "ppo_train_kernel<critic> (fused fwd+loss+bwd+dW)" + (", agents of a row aggregated" if aggregated else ""),
+                  "bound": "mfma", "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
+                  "traffic": (traffic.get("ppo_train_kernel<critic>", {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c, "rows_per_launch": rows_c}
+        roof_a = {"kernel": "ppo_train_kernel<actor> (fused fwd+loss+bwd+dW)", "bound": "mfma", "achieved": tf_a,
+                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_a / F32_MFMA_PEAK_TFLOPS,
+                  "traffic": (traffic.get("ppo_train_kernel<actor>", {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "avg_launch_ms": avg["actor_grad"], "flop_per_launch": flop_a, "rows_per_launch": rows}
+        # "roofline" = the dominant kernel of the update (most time per update)
+        if avg["actor_grad"] >= avg["critic_grad"]:
+            out["roofline"], out["roofline_critic"] = roof_a, roof_c
+        else:
+            out["roofline"], out["roofline_actor"] = roof_c, roof_a
         gae_bytes = 17 * T * E * A + 4 * E * A
         gbs = gae_bytes / (avg["gae"] * 1e-3) / 1e9
         out["roofline_gae"] = {"kernel": "gae_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_peak": gbs / 6290.0,
                                "traffic": (traffic.get("gae_kernel", {}).get("hbm_bytes_corrected") if default_shape else None),
                                "avg_launch_us": avg["gae"] * 1e3, "bytes_per_launch": gae_bytes}
-        out["roofline_actor"] = {"kernel": "ppo_train_kernel<actor>", "bound": "mfma", "achieved": tf_a,
-                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_a / F32_MFMA_PEAK_TFLOPS,
-                                 "avg_launch_ms": avg["actor_grad"], "flop_per_launch": flop_a}
         adam_bytes = 28 * L.P
         out["roofline_adam"] = {"kernel": "clip_adam_kernel", "bound": "hbm (launch-bound at 77K params)",
                                 "achieved": adam_bytes / (avg["clip_adam"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

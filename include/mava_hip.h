@@ -121,6 +121,12 @@ int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_i
                              long idx_base, int Rb, int A, float clip_eps, float vf_coef,
                              float* slab, long slab_stride, int n_slab, mava_stream_t s);
 
+/* Measurement / reproducibility knob for mava_ppo_critic_grad_f32 (default 1).  With a centralised critic the
+ * reference tiles one global state to all A agents (mava/wrappers/jumanji.py:57-58) and evaluates the critic on
+ * A identical rows; when x_share == A (<= 8) the kernel evaluates each (t,e) row once and back-propagates the sum
+ * of its agents' loss gradients - mathematically the same gradient.  0 restores one pass per agent row. */
+int mava_ppo_set_critic_aggregation(int on);
+
 /* ---- synthetic RWARE-shaped environment (measurement stand-in for the third-party Jumanji
  *      RobotWarehouse stepped at mava/systems/ppo/ff_mappo.py:88).  Wrapper semantics follow
  *      mava/wrappers/observation.py:41-53, jumanji.py:53-59,128-143, auto_reset_wrapper.py:88-101

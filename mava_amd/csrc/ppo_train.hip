@@ -34,6 +34,8 @@ struct TrainTask {
   const float* x;          // (rows_x, din)
   int din, no, xshare, xv;
   int A;                   // agent rows per (t,e) index
+  int agg;                 // critic only: 1, or A when the A agents of an index share one input row and are
+                           // aggregated into it (one network pass per (t,e) row instead of A identical ones)
   const int32_t* idx;      // minibatch (t*E+e) indices, or null => idx_base + b
   long idx_base;
   int Rb;                  // (t,e) rows in the minibatch; agent rows R = Rb * A
@@ -187,8 +189,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
   const int srow = tid >> 3, l8 = tid & 7;  // staging role: row srow of the tile, 8 threads per row
   const int din = tk.din, no = tk.no;
-  const long R = (long)tk.Rb * tk.A;
-  const float invR = 1.0f / (float)R;
+  // rows the network is evaluated on: agent rows, or (t,e) rows when the agents of a row are aggregated (the
+  // .mean() of the reference still runs over all Rb*A agent rows)
+  const long R = (!ACTOR && tk.agg > 1) ? (long)tk.Rb : (long)tk.Rb * tk.A;
+  const float invR = 1.0f / (float)((long)tk.Rb * tk.A);
   constexpr int NR = 4 * KT1;  // staged floats per thread (32*KT1 columns / 8 threads)
 
   mlp_fill_lds<NO>(lds, tk.params, din, no, 256);
@@ -264,6 +268,9 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   constexpr int GR = ACTOR ? 64 / NO : 32;     // rows per pass (actor)
   const int lo = ACTOR ? (lane & (NO - 1)) : 0;  // this lane's output index (actor)
   auto loss_row = [&](int q) -> int { return ACTOR ? (8 * w + q * GR + lane / NO) : j; };
+  // aggregated critic: the 8 (wave, half) copies of loss row j each take one agent of that row
+  const int slot = 2 * w + h;
+  const int slot_c = (!ACTOR && tk.agg > 1) ? (slot < tk.agg ? slot : 0) : 0;
   // per-row loss inputs (plain scalars, no aggregates: they must stay in registers)
   //   act: action ; f0, f1: actor old_logp, advantage / critic old_value, target ; m: raw mask byte of output lo
   auto load_row = [&](long fr, int& act, float& f0, float& f1, uint32_t& m) {
@@ -276,15 +283,17 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       if (mk != nullptr) m = *mk;
     } else {
       act = 0;
-      f0 = tk.old_value[fr];
-      f1 = tk.targets[fr];
+      const long fa = (tk.agg > 1) ? fr * tk.agg + slot_c : fr;  // agent slot_c of (t,e) row fr
+      f0 = tk.old_value[fa];
+      f1 = tk.targets[fa];
       m = 0u;
     }
   };
   // Row cursors: agent-row q = 32*tile + r of the minibatch is (b, a) = (q / A, q % A), index idx[b], trajectory
   // row idx[b]*A + a.  A thread's q advances by the same 32*gridDim.x every tile, so (b, a) are advanced
   // incrementally - no integer division inside the tile loop.  Rows past the end clamp to row R-1.
-  const uint32_t Au = (uint32_t)tk.A;
+  const uint32_t Au = (!ACTOR && tk.agg > 1) ? 1u : (uint32_t)tk.A;
+
   const uint32_t q_step = 32u * gridDim.x, b_step = q_step / Au, a_step = q_step % Au;
   const uint32_t b_last = (uint32_t)(R - 1) / Au, a_last = (uint32_t)(R - 1) % Au;
   struct Cursor { uint32_t q, b, a; };
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       cursor_gather(cl[q], pl_next[q], al_next[q]);
-      load_row((long)pl_next[q] * tk.A + al_next[q], r_act[q], r_f0[q], r_f1[q], r_m[q]);
+      load_row((long)((uint32_t)pl_next[q] * Au + al_next[q]), r_act[q], r_f0[q], r_f1[q], r_m[q]);
     }
     stage_commit(xr);
     cursor_advance(cs);
@@ -601,8 +610,23 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
       const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
       const float g2 = inside ? (1.0f - g1) : 0.0f;
-      const float dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2) * invR) : 0.0f;
-      if (valid && w == 0 && h == 0) {
+      float dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2) * invR) : 0.0f;
+      if (tk.agg > 1) {
+        // this lane evaluated agent `slot` of row j: the value is shared by the row's agents, so the backward
+        // pass runs once on the sum of their loss gradients (d loss / d theta = sum_a dy_a * d v / d theta)
+        const bool mine = valid && slot < tk.agg;
+        dy0 = mine ? dy0 : 0.0f;
+        if (mine) {
+          loss_a += 0.5f * fmaxf(l1, l2) * invR;
+          ab3 += dy0;
+        }
+        DY[slot * LDT + j] = dy0;
+        __syncthreads();  // B2
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) sum += DY[a * LDT + j];  // fixed order: identical in every lane
+        dy0 = sum;
+      } else if (valid && w == 0 && h == 0) {
         loss_a += 0.5f * fmaxf(l1, l2) * invR;
         ab3 += dy0;
       }
@@ -764,16 +788,19 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
       if (j == 0) slab[oW3 + fbase + (r & 3) + 8 * (r >> 2)] = v;
     }
-    float v = ab3;
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    if (tid == 0) slab[oB3] = v;
-    if (w == 0) {
-      for (int o = 32; o > 0; o >>= 1) loss_a += __shfl_down(loss_a, o, 64);
-      if (lane == 0) {
-        slab[P] = loss_a;
-        slab[P + 1] = 0.0f;
-      }
+    // db3 and the value loss: per-lane partials of every lane that took part (wave 0 / half 0 only, or one agent
+    // per (wave, half) when aggregated) -> wave sums -> fixed-order sum over the 4 waves
+    float v = ab3, l = loss_a;
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_down(v, o, 64);
+      l += __shfl_down(l, o, 64);
+    }
+    if (lane == 0) { red[2 * w] = v; red[2 * w + 1] = l; }
+    __syncthreads();
+    if (tid == 0) {
+      slab[oB3] = ((red[0] + red[2]) + red[4]) + red[6];
+      slab[P] = ((red[1] + red[3]) + red[5]) + red[7];
+      slab[P + 1] = 0.0f;
     }
   }
 }
@@ -837,6 +864,15 @@ extern "C" int mava_debug_set_stamps(unsigned long long* p) {
   return MAVA_OK;
 }
 
+static int g_critic_agg = 1;
+// 1 (default): when the A agents of a (t,e) row share one critic input row (x_share == A <= 8) the critic kernel
+// evaluates the network once per row and back-propagates the sum of the agents' loss gradients - the same gradient
+// as A identical passes, at 1/A of the matrix work.  0: one pass per agent row (the reference's arithmetic order).
+extern "C" int mava_ppo_set_critic_aggregation(int on) {
+  g_critic_agg = on ? 1 : 0;
+  return MAVA_OK;
+}
+
 extern "C" int mava_adv_stats_blocks(void) { return STATS_BLOCKS; }
 
 extern "C" int mava_adv_stats_f64(const float* adv, const int32_t* idx, long idx_base, int Rb, int A,
@@ -865,7 +901,7 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
   MAVA_ARG_CHECK(params && agents_view && action && old_log_prob && advantages && adv_stats && slab, 3,
                  "mava_ppo_actor_grad_f32: null pointer argument");
   TrainTask tk = {};
-  tk.params = params; tk.x = agents_view; tk.din = din; tk.no = n_actions; tk.xshare = 1;
+  tk.params = params; tk.x = agents_view; tk.din = din; tk.no = n_actions; tk.xshare = 1; tk.agg = 1;
   tk.xv = pick_xv(agents_view, din); tk.A = A; tk.idx = idx; tk.idx_base = idx_base; tk.Rb = Rb;
   tk.mask = action_mask; tk.action = action; tk.old_logp = old_log_prob; tk.adv = advantages;
   tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
@@ -889,7 +925,11 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
   MAVA_ARG_CHECK(params && critic_input && old_value && targets && slab, 3,
                  "mava_ppo_critic_grad_f32: null pointer argument");
   TrainTask tk = {};
-  tk.params = params; tk.x = critic_input; tk.din = din; tk.no = 1; tk.xshare = x_share;
+  tk.params = params; tk.x = critic_input; tk.din = din; tk.no = 1; tk.xshare = x_share; tk.agg = 1;
+  if (g_critic_agg && A > 1 && A <= 8 && x_share == A) {  // input row of index p is row p itself
+    tk.agg = A;
+    tk.xshare = 1;
+  }
   tk.xv = pick_xv(critic_input, din); tk.A = A; tk.idx = idx; tk.idx_base = idx_base; tk.Rb = Rb;
   tk.old_value = old_value; tk.targets = targets; tk.clip_eps = clip_eps; tk.vf_coef = vf_coef;
   tk.slab = slab; tk.slab_stride = slab_stride;

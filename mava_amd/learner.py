@@ -230,8 +230,12 @@ class FFLearner:
                     cx = rep.global_state[t].view(-1, self.Oc)
                 else:
                     cx = av
+                # a critic input row shared by the A agents of an env (critic_share == A) is evaluated once and its
+                # value written to all A agent slots - the same numbers as A identical forward passes
+                shared = self.critic_share == self.A and self.A > 1
                 self._timed("policy_step", ops.policy_step, pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
-                                critic_share=self.critic_share, critic_rows=EA, seed=self.seed, step=step,
+                                critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
+                                value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
                                 row_offset=(self.rank * self.U + u) * EA,
                                 out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)))
                 last = t == self.T - 1

@@ -282,10 +282,20 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab):
 
 @pytest.mark.parametrize("TE,A,O,Rb,use_idx,shared,n_slab", [(64, 4, 66, 64, False, True, 3), (200, 4, 66, 77, True, True, 8),
                                                              (96, 2, 30, 40, True, False, 2), (33, 1, 9, 33, True, True, 1),
-                                                             (4096, 4, 66, 2048, True, True, 256)])
-def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab):
+                                                             (4096, 4, 66, 2048, True, True, 256),
+                                                             (150, 8, 20, 101, True, True, 5), (70, 2, 50, 70, False, True, 4)])
+@pytest.mark.parametrize("agg", [1, 0])
+def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, agg):
+    """agg=1: agents that share one critic input row are aggregated (one network pass per (t,e) row, the sum of
+    their loss gradients back-propagated); agg=0: one pass per agent row.  Both must match the oracle, which
+    follows the reference and evaluates every agent row."""
     from mava_amd import ops
+    from mava_amd._lib import lib
     from oracle import torch_ref
+
+    if agg == 0 and not shared:
+        pytest.skip("aggregation only applies to shared critic inputs")
+    lib().mava_ppo_set_critic_aggregation(agg)
 
     rng = np.random.default_rng(TE + O)
     av, gs, mask, action, old_lp, adv, old_v, tgt = _traj(rng, TE, A, O, 5, shared_gs=shared)
@@ -302,8 +312,11 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab):
 
     P = flat.size
     slab = torch.zeros((n_slab, P + 2), device=dev)
-    ops.ppo_critic_grad(_t(flat, dev), _t(gs, dev), share, _t(old_v, dev), _t(tgt, dev), _t(idx, dev) if use_idx else None,
-                        0, Rb, A, 0.2, 0.5, slab)
+    try:
+        ops.ppo_critic_grad(_t(flat, dev), _t(gs, dev), share, _t(old_v, dev), _t(tgt, dev), _t(idx, dev) if use_idx else None,
+                            0, Rb, A, 0.2, 0.5, slab)
+    finally:
+        lib().mava_ppo_set_critic_aggregation(1)
     out = torch.zeros(P + 2, device=dev)
     ops.slab_reduce(slab, P + 2, out)
     torch.cuda.synchronize()

@@ -50,52 +50,77 @@ struct SynthArgs {
   int is_reset;
 };
 
-__device__ __forceinline__ float synth_raw_feature(uint32_t ent, int f, const SynthArgs& a) {
-  // raw view feature f of entity ent = env_id*A + agent (identical formula in oracle/synth_env.py)
-  if (f < 2) {
-    Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
-    return (float)((f == 0 ? cm.x : cm.y) % 10u);
+// One thread per 16-feature CHUNK of a raw view (= one Philox block: every draw is a pure function of
+// (entity, step, word group) on the counter-based RNG, so a thread owns 16 consecutive output floats and no thread
+// needs another thread's draw), written with 8-byte stores where the row layout allows; the chunk-0 thread also
+// writes the row's one-hot id and its two grid coordinates.  A thread per output float - the first version -
+// recomputed the same Philox block 16 times and was VALU-bound at 13 us per step.  Then one thread per
+// (env, agent) for the small per-agent / per-env data.
+__device__ __forceinline__ void store_run(float* dst, const float (&v)[16], int n, bool vec2) {
+  if (vec2 && n == 16) {
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) *reinterpret_cast<float2*>(dst + q) = make_float2(v[q], v[q + 1]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (q < n) dst[q] = v[q];
   }
-  const int c = (f - 2) >> 4, q = (f - 2) & 15;
-  Philox4 r = philox4x32_10(ent, a.t, (uint32_t)c, ENV_STREAM, a.seed_lo, a.seed_hi);
-  const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
-  return (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
 }
 
-// Flat, fully coalesced generation: one thread per OUTPUT float of agents_view and global_state (every
-// value is a pure function of (entity, step, feature) on the counter-based RNG, so no thread ever needs
-// another thread's draw), followed by one thread per (env, agent) for the small per-agent / per-env data.
 __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
   const uint32_t E = a.E, A = a.A, O = a.O, W = A + O;
-  const uint32_t n_av = E * A * W;
-  const uint32_t gsw = a.S > 0 ? (uint32_t)a.S : A * O;  // width of one global-state row
-  const uint32_t n_gs = E * (uint32_t)a.gs_tiles * gsw;
+  const uint32_t nch = max(1u, (O - 2 + 15) / 16);        // bit chunks per raw view (>= 1: chunk 0 also writes id + coordinates)
+  const uint32_t n_view = E * A * nch;                    // (entity, chunk) threads
+  const uint32_t gsw = a.S > 0 ? (uint32_t)a.S : A * O;   // width of one global-state row
+  const uint32_t nch_s = a.S > 0 ? max(1u, ((uint32_t)a.S - 2 + 15) / 16) : 0;
+  const uint32_t n_state = E * nch_s;                     // (env, chunk) threads of an independent state vector
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid < n_av) {
-    const uint32_t row = gid / W, col = gid - row * W;
-    const uint32_t e = row / A, ag = row - e * A;
-    float v;
-    if (col < A) {
-      v = (col == ag) ? 1.0f : 0.0f;
-    } else {
-      v = synth_raw_feature((a.env_offset + e) * A + ag, (int)(col - A), a);
+  if (gid < n_view + n_state) {
+    const bool is_state = gid >= n_view;
+    const uint32_t i = is_state ? gid - n_view : gid;
+    const uint32_t per = is_state ? nch_s : nch;
+    const uint32_t row = i / per, c = i - row * per;      // row = entity (env*A + agent) or env
+    const uint32_t e = is_state ? row : row / A, ag = is_state ? 0u : row - e * A;
+    const uint32_t ent = is_state ? (0x80000000u | (a.env_offset + e)) : ((a.env_offset + e) * A + ag);
+    const uint32_t nf = is_state ? (uint32_t)a.S : O;     // features of this raw row
+    const Philox4 r = philox4x32_10(ent, a.t, c, ENV_STREAM, a.seed_lo, a.seed_hi);
+    const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
+    const uint32_t f0 = 2 + 16 * c;                       // first feature of the chunk
+    const int n = (int)min(16u, nf - f0);
+    float c0 = 0.0f, c1 = 0.0f;
+    if (c == 0) {                                          // the row's grid coordinates (features 0, 1)
+      const Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
+      c0 = (float)(cm.x % 10u);
+      c1 = (float)(cm.y % 10u);
     }
-    a.agents_view[gid] = v;
+    if (!is_state) {
+      float* av = a.agents_view + (long)row * W;
+      store_run(av + A + f0, v, n, ((W & 1u) == 0) && (((A + f0) & 1u) == 0));
+      if (c == 0) {
+        for (uint32_t k2 = 0; k2 < A; ++k2) av[k2] = (k2 == ag) ? 1.0f : 0.0f;
+        av[A] = c0;
+        av[A + 1] = c1;
+      }
+      if (a.S == 0) {                                      // global state = concatenated raw views
+        for (int tile = 0; tile < a.gs_tiles; ++tile) {
+          float* gs = a.global_state + ((long)e * a.gs_tiles + tile) * gsw + (long)ag * O;
+          store_run(gs + f0, v, n, ((gsw & 1u) == 0) && ((O & 1u) == 0));
+          if (c == 0) { gs[0] = c0; gs[1] = c1; }
+        }
+      }
+    } else {
+      for (int tile = 0; tile < a.gs_tiles; ++tile) {
+        float* gs = a.global_state + ((long)e * a.gs_tiles + tile) * gsw;
+        store_run(gs + f0, v, n, (gsw & 1u) == 0);
+        if (c == 0) { gs[0] = c0; gs[1] = c1; }
+      }
+    }
     return;
   }
-  if (gid < n_av + n_gs) {
-    const uint32_t i = gid - n_av;
-    const uint32_t et = i / gsw, c = i - et * gsw;   // (env, tile), column in the state row
-    const uint32_t e = et / (uint32_t)a.gs_tiles;
-    if (a.S > 0) {
-      a.global_state[i] = synth_raw_feature(0x80000000u | (a.env_offset + e), (int)c, a);
-    } else {
-      const uint32_t ag = c / O, f = c - ag * O;
-      a.global_state[i] = synth_raw_feature((a.env_offset + e) * A + ag, (int)f, a);
-    }
-    return;
-  }
-  const uint32_t k = gid - n_av - n_gs;
+  const uint32_t k = gid - n_view - n_state;
   if (k >= E * A) return;
   const uint32_t e = k / A, ag = k - e * A;
   const uint32_t env_id = a.env_offset + e;
@@ -171,8 +196,12 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
   a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;
   a.reward = reward; a.done = done; a.info_return = info_return; a.info_length = info_length;
   a.info_terminal = info_terminal; a.is_reset = is_reset;
-  const long total = (long)E * A * (A + O) + (long)E * gs_tiles * (state_dim > 0 ? state_dim : A * O) + (long)E * A;
-  MAVA_ARG_CHECK(total < (1L << 32), 4, "mava_synth_rware_step: %ld output elements exceed 32-bit indexing", total);
+  MAVA_ARG_CHECK(state_dim == 0 || state_dim >= 2, 1, "mava_synth_rware_step: state_dim must be 0 or >= 2");
+  const long nch = (O - 2 + 15) / 16 > 0 ? (O - 2 + 15) / 16 : 1;
+  const long nch_s = state_dim > 0 ? ((state_dim - 2 + 15) / 16 > 0 ? (state_dim - 2 + 15) / 16 : 1) : 0;
+  const long total = (long)E * A * nch + (long)E * nch_s + (long)E * A;
+  MAVA_ARG_CHECK(total < (1L << 32) && (long)E * A * (A + O) < (1L << 31), 4,
+                 "mava_synth_rware_step: %ld threads exceed 32-bit indexing", total);
   hipLaunchKernelGGL(synth_rware_kernel, dim3(mava_cdiv(total, 256)), dim3(256), 0, s, a);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;

@@ -22,22 +22,29 @@ def _cfg(system, scenario_agents, E, T, K, M, U, extra=()):
     return cfg
 
 
-def test_synthetic_env_bit_exact(dev):
+@pytest.mark.parametrize("E,A,O,nA,S,tiled", [(37, 3, 21, 5, 0, False), (16, 4, 66, 5, 0, False), (9, 5, 30, 6, 27, False),
+                                              (12, 2, 2, 3, 0, False), (10, 4, 66, 5, 0, True), (7, 3, 19, 4, 40, True)])
+def test_synthetic_env_bit_exact(dev, E, A, O, nA, S, tiled):
+    """Row widths that take the 8-byte store path (even) and the scalar one (odd), a raw view with no bit chunk
+    (O = 2), an independent state vector (S > 0, SMAX-shaped) and the tiled (per-agent) global state."""
     from mava_amd.envs import SyntheticRware
 
-    E, A, O, nA = 37, 3, 21, 5
-    env = SyntheticRware(E, A, O, nA, time_limit=6, add_global_state=True, seed=1234, env_offset=1000, device=dev)
-    ora = SynthRware(E, A, O, nA, time_limit=6, seed=1234, env_offset=1000)
+    env = SyntheticRware(E, A, O, nA, time_limit=6, add_global_state=True, seed=1234, env_offset=1000, device=dev,
+                         state_dim=S, tile_global_state=tiled)
+    ora = SynthRware(E, A, O, nA, time_limit=6, seed=1234, env_offset=1000, state_dim=S, gs_tiles=A if tiled else 1)
     state, ts = env.reset()
     o = ora.reset(0)
     assert np.array_equal(ts.observation.agents_view.cpu().numpy(), o["agents_view"])
-    assert np.array_equal(ts.observation.global_state.cpu().numpy(), np.repeat(o["global_state"], A, 1))
+    want_gs = o["global_state"] if tiled else np.repeat(o["global_state"], A, 1)
+    assert np.array_equal(ts.observation.global_state.cpu().numpy(), want_gs)
     assert np.array_equal(ts.observation.action_mask.cpu().numpy(), o["action_mask"])
     n_term = 0
     for t in range(1, 40):
         state, ts = env.step(state, torch.zeros((E, A), dtype=torch.int32, device=dev))
         o, r, d, info = ora.step(t)
         assert np.array_equal(ts.observation.agents_view.cpu().numpy(), o["agents_view"]), t
+        assert np.array_equal(ts.observation.global_state.cpu().numpy(),
+                              o["global_state"] if tiled else np.repeat(o["global_state"], A, 1)), t
         assert np.array_equal(ts.observation.action_mask.cpu().numpy(), o["action_mask"]), t
         assert np.array_equal(ts.observation.step_count.cpu().numpy(), o["step_count"]), t
         assert np.array_equal(ts.reward.cpu().numpy(), r), t
@@ -51,7 +58,8 @@ def test_synthetic_env_bit_exact(dev):
     # agent ids are one-hot, global state is the concatenation of the raw views
     av = ts.observation.agents_view.cpu().numpy()
     assert np.array_equal(av[:, :, :A], np.broadcast_to(np.eye(A, dtype=np.float32), (E, A, A)))
-    assert np.array_equal(ts.observation.global_state.cpu().numpy()[:, 0], av[:, :, A:].reshape(E, A * O))
+    if S == 0:
+        assert np.array_equal(ts.observation.global_state.cpu().numpy()[:, 0], av[:, :, A:].reshape(E, A * O))
 
 
 @pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])

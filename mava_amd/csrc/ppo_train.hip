@@ -67,7 +67,7 @@ struct TrainTask {
 
 // LDS carve (floats) computed on the host per launch (din / NO dependent), checked against 160 KiB.
 struct TrainLdsLayout {
-  int h1t, h2t, dz2t, yp, dy, xs, misc, end;
+  int h1t, h2t, dz2t, dz1t, yp, dy, xs, misc, end;  // dz1t == h2t: the dz1^T tile aliases h2^T (extra barrier D')
   int ldx;  // row stride of the staged x tile: 32*KT1 + 4 floats (16-byte rows, an odd number of 16-byte slots =>
             // conflict-free ds_read_b128 row walks in P1 and ds_write_b128 staging)
 };
@@ -86,6 +86,12 @@ TrainLdsLayout make_layout(int kt1) {
   L.xs = (L.dy + 32 * LDT + 3) & ~3;  // [32][ldx] gathered x tile, zero padded to 32*KT1 columns, 16-byte aligned
   L.misc = L.xs + 32 * L.ldx;  // 16-byte aligned (xs and 32*ldx are)
   L.end = L.misc + 16;
+  // dz1^T gets its own tile when the CU's 160 KiB allow (narrow inputs): one barrier less per row tile
+  L.dz1t = L.h2t;
+  if ((size_t)(L.end + tile) * sizeof(float) <= 163840) {
+    L.dz1t = L.end;
+    L.end += tile;
+  }
   return L;
 }
 
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   float* const W3s = lds + MlpLds<NO>::W3;
   float* const H1T = lds + L.h1t;
   float* const H2T = lds + L.h2t;
-  float* const DZ1T = H2T;  // alias, see barrier D'
+  float* const DZ1T = lds + L.dz1t;  // own tile, or an alias of h2^T behind barrier D'
   float* const DZ2T = lds + L.dz2t;
   float* const YP = lds + L.yp;
   float* const DY = lds + L.dy;
@@ -433,8 +439,12 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
             xn[0] = v0.x; xn[1] = v0.y; xn[2] = v0.z; xn[3] = v0.w;
             xn[4] = v1.x; xn[5] = v1.y; xn[6] = v1.z; xn[7] = v1.w;
           }
+          // a batch whose 16 inputs all lie past the ones column (k > din) multiplies zeros: skipped (uniform branch;
+          // its operand loads still run, the ring stays in step).  din = 70 -> 5 of 6 batches, 264 -> 17 of 18.
+          if (16 * b <= din) {
 #pragma unroll
-          for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[d][s], xo[d][s], h1);
+            for (int s = 0; s < 8; ++s) h1 = MFMA32(wr[d][s], xo[d][s], h1);
+          }
           // refill the slot consumed ONE batch ago (its MFMAs have retired: no write-after-read wait on
           // operands still being read) with batch b-1+RD
           if (!W1_RESIDENT) {
@@ -677,7 +687,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       for (int s2 = 0; s2 < 16; ++s2) gW3 = MFMA32(oa[s2], ob[s2], gW3);
     }
     STAMP(3);
-    __syncthreads();  // D': every reader of h2^T is done; the tile is reused for dz1^T
+    if (L.dz1t == L.h2t) __syncthreads();  // D': every reader of h2^T is done; the tile is reused for dz1^T
     {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

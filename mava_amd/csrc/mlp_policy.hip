@@ -11,7 +11,7 @@
 // three layers in registers (mlp_core.h).  Blocks [0, nblk_actor) serve the actor, the rest
 // the critic, so one launch covers 2 * ceil(R/32) wave-tiles (1024 at the BASELINE config-2
 // shape: one per SIMD).  W2/W3/biases are staged in LDS once per block.
-#include "mlp_core.h"
+#include "mlp_coop_body.h"
 
 namespace {
 
@@ -72,6 +72,83 @@ struct StepOut {
   const int32_t* forced_action;  // optional: evaluate log_prob of given actions instead of sampling
 };
 
+// Per-wave actor: block `bid` of the `nblk` actor blocks; each wave carries whole 32-row tiles through the three
+// layers in registers, then masks, samples (Gumbel-max on Philox) and scores the action.
+template <int NOA>
+__device__ __forceinline__ void actor_step_body(const FwdTask& actor, float* lds, int bid, int nblk,
+                                                const uint8_t* __restrict__ mask, uint32_t seed_lo, uint32_t seed_hi,
+                                                uint32_t step, uint32_t row_offset, int greedy, const StepOut& out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
+  mlp_fill_lds<NOA>(lds, actor.params, actor.din, actor.no, 256);
+  __syncthreads();
+  const int ntiles = (actor.R + 31) / 32;
+  for (int tile = bid * 4 + w; tile < ntiles; tile += nblk * 4) {
+    const int row = tile * 32 + j;
+    const bool valid = row < actor.R;
+    float y[NOA];
+    forward_tile<NOA>(actor, lds, row, valid, h, j, y);
+    const int no = actor.no;
+    Categorical<NOA> cat;
+    cat.build(y, (mask != nullptr && valid) ? (mask + (long)row * no) : nullptr, no);
+    int a = 0;
+    if (out.forced_action != nullptr) {
+      a = valid ? out.forced_action[row] : 0;
+    } else if (greedy) {
+      float best = -FLT_MAX;
+#pragma unroll
+      for (int o = 0; o < NOA; ++o)
+        if (o < no && cat.z[o] > best) { best = cat.z[o]; a = o; }
+    } else {
+      // Gumbel-max: argmax_o z[o] - log(-log(u_o)), first index wins ties
+      float best = -FLT_MAX;
+      const uint32_t gid = row_offset + (uint32_t)row;
+#pragma unroll
+      for (int c = 0; c < (NOA + 3) / 4; ++c) {
+        Philox4 rnd = philox4x32_10(gid, step, (uint32_t)c, 0x504f4c49u /*"POLI"*/, seed_lo, seed_hi);
+        const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = 4 * c + q;
+          if (o < NOA && o < no) {
+            const float u = u01_open(wds[q]);
+            const float g = -logf(-logf(u));
+            const float sc = cat.z[o] + g;
+            if (sc > best) { best = sc; a = o; }
+          }
+        }
+      }
+    }
+    float lp = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NOA; ++o)
+      if (o == a) lp = cat.logp[o];
+    if (valid && h == 0) {
+      out.action[row] = a;
+      out.log_prob[row] = lp;
+      if (out.logits != nullptr)
+        for (int o = 0; o < no && o < NOA; ++o) out.logits[(long)row * no + o] = y[o];
+    }
+  }
+}
+
+// Hybrid acting step: blocks [0, nblk_actor) run the per-wave actor, the remaining blocks the BLOCK-COOPERATIVE
+// critic (4 waves per 32-row tile, coop_body) - for launches with few critic tiles (one value per env when the
+// agents share the critic input: 128 tiles at the BASELINE shape).  A wave that carries a whole tile through the
+// 264-wide critic is a ~26 us chain of ~900 MFMAs and used to set the step's duration while most SIMDs idled;
+// split four ways it is shorter than the actor's chain, and with <= 256 blocks every block has its own CU.
+template <int NOA, int KT1C>
+__global__ __launch_bounds__(256, 1) void policy_hybrid_kernel(FwdTask actor, coop::CoopTask critic, coop::CoopLds Lc,
+                                                               int nblk_actor, const uint8_t* __restrict__ mask,
+                                                               uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
+                                                               uint32_t row_offset, int greedy, StepOut out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < nblk_actor) {
+    actor_step_body<NOA>(actor, lds, (int)blockIdx.x, nblk_actor, mask, seed_lo, seed_hi, step, row_offset, greedy, out);
+  } else {
+    coop::coop_body<1, KT1C, coop::MODE_VALUE>(critic, Lc, lds, (int)blockIdx.x - nblk_actor, (int)gridDim.x - nblk_actor);
+  }
+}
+
 template <int NOA>
 __global__ __launch_bounds__(256, 2) void policy_step_kernel(FwdTask actor, FwdTask critic,
                                                              int nblk_actor,
@@ -84,56 +161,7 @@ __global__ __launch_bounds__(256, 2) void policy_step_kernel(FwdTask actor, FwdT
   const bool is_actor = (int)blockIdx.x < nblk_actor;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
   if (is_actor) {
-    mlp_fill_lds<NOA>(lds, actor.params, actor.din, actor.no, 256);
-    __syncthreads();
-    const int ntiles = (actor.R + 31) / 32;
-    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nblk_actor * 4) {
-      const int row = tile * 32 + j;
-      const bool valid = row < actor.R;
-      float y[NOA];
-      forward_tile<NOA>(actor, lds, row, valid, h, j, y);
-      const int no = actor.no;
-      Categorical<NOA> cat;
-      cat.build(y, (mask != nullptr && valid) ? (mask + (long)row * no) : nullptr, no);
-      int a = 0;
-      if (out.forced_action != nullptr) {
-        a = valid ? out.forced_action[row] : 0;
-      } else if (greedy) {
-        float best = -FLT_MAX;
-#pragma unroll
-        for (int o = 0; o < NOA; ++o)
-          if (o < no && cat.z[o] > best) { best = cat.z[o]; a = o; }
-      } else {
-        // Gumbel-max: argmax_o z[o] - log(-log(u_o)), first index wins ties
-        float best = -FLT_MAX;
-        const uint32_t gid = row_offset + (uint32_t)row;
-#pragma unroll
-        for (int c = 0; c < (NOA + 3) / 4; ++c) {
-          Philox4 rnd = philox4x32_10(gid, step, (uint32_t)c, 0x504f4c49u /*"POLI"*/, seed_lo, seed_hi);
-          const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int o = 4 * c + q;
-            if (o < NOA && o < no) {
-              const float u = u01_open(wds[q]);
-              const float g = -logf(-logf(u));
-              const float sc = cat.z[o] + g;
-              if (sc > best) { best = sc; a = o; }
-            }
-          }
-        }
-      }
-      float lp = 0.0f;
-#pragma unroll
-      for (int o = 0; o < NOA; ++o)
-        if (o == a) lp = cat.logp[o];
-      if (valid && h == 0) {
-        out.action[row] = a;
-        out.log_prob[row] = lp;
-        if (out.logits != nullptr)
-          for (int o = 0; o < no && o < NOA; ++o) out.logits[(long)row * no + o] = y[o];
-      }
-    }
+    actor_step_body<NOA>(actor, lds, (int)blockIdx.x, nblk_actor, mask, seed_lo, seed_hi, step, row_offset, greedy, out);
   } else {
     const int bid = blockIdx.x - nblk_actor;
     const int nblk = gridDim.x - nblk_actor;
@@ -162,6 +190,48 @@ int pick_xv(const float* x, int din) {
 template <int NO>
 size_t lds_bytes() { return (size_t)MlpLds<NO>::END * sizeof(float); }
 
+template <int NOA, int KT1C>
+int launch_hybrid_t(const FwdTask& ta, const coop::CoopTask& ck, int nba, int nbc, const uint8_t* mask, uint32_t slo,
+                    uint32_t shi, uint32_t step, uint32_t row_offset, int greedy, const StepOut& so, hipStream_t s) {
+  const coop::CoopLds Lc = coop::make_coop_layout<1>(KT1C);
+  size_t lb = (size_t)Lc.end * sizeof(float);
+  if (lds_bytes<NOA>() > lb) lb = lds_bytes<NOA>();
+  MAVA_ARG_CHECK(lb <= 163840, 8, "policy hybrid: %zu bytes of LDS needed exceed the 160 KiB of a CU", lb);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)policy_hybrid_kernel<NOA, KT1C>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((policy_hybrid_kernel<NOA, KT1C>), dim3(nba + nbc), dim3(256), lb, s, ta, ck, Lc, nba, mask, slo,
+                     shi, step, row_offset, greedy, so);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+// returns 1 when the shape is not instantiated (caller falls back to the per-wave kernel)
+int launch_hybrid(const FwdTask& ta, const coop::CoopTask& ck, int nba, int nbc, int n_actions, const uint8_t* mask,
+                  uint32_t slo, uint32_t shi, uint32_t step, uint32_t row_offset, int greedy, const StepOut& so,
+                  hipStream_t s) {
+  const int kt = (ck.din + 31) / 32;
+#define HY(NOA, KT) return launch_hybrid_t<NOA, KT>(ta, ck, nba, nbc, mask, slo, shi, step, row_offset, greedy, so, s)
+#define HYK(NOA)                                   \
+  switch (kt) {                                    \
+    case 1: HY(NOA, 1);                            \
+    case 2: HY(NOA, 2);                            \
+    case 3: HY(NOA, 3);                            \
+    case 4: HY(NOA, 4);                            \
+    case 5: case 6: HY(NOA, 6);                    \
+    case 7: case 8: case 9: HY(NOA, 9);            \
+    default: return 1;                             \
+  }
+  if (n_actions <= 8) { HYK(8) }
+  if (n_actions <= 16) { HYK(16) }
+  HYK(32)
+#undef HYK
+#undef HY
+}
+
 }  // namespace
 
 // block-cooperative kernels (mlp_coop.hip)
@@ -173,9 +243,10 @@ int mava_coop_value(const float* params, int din, const float* x, int x_share, i
 int mava_coop_raw(const float* params, int din, int n_out, const float* x, int x_share, int rows, float* out,
                   hipStream_t s);
 
-// 0 (default): per-wave register-resident kernel, one launch for actor + critic (fastest at the per-step
-// sizes of the rollout: the block-cooperative kernels pay a per-launch W2 staging cost that two 32-row tiles
-// per block cannot amortise - 49.6 vs 43.9 us per step at 16384 rows on MI355X); 2: block-cooperative kernels
+// 0 (default): per-wave register-resident kernel, one launch for actor + critic - as a HYBRID launch (cooperative
+// critic blocks, policy_hybrid_kernel) when the critic has at most 128 tiles; 1: per-wave kernel always;
+// 2: block-cooperative kernels, one launch per network (they pay a per-launch W2 staging cost that two 32-row
+// tiles per block cannot amortise: 49.6 vs 43.9 us per step at 16384 rows per network on MI355X)
 static int g_policy_variant = 0;
 extern "C" int mava_policy_set_variant(int v) {
   g_policy_variant = v;
@@ -246,6 +317,21 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
     return rc;
   }
   FwdTask ta = {actor_params, agents_view, actor_din, n_actions, 1, pick_xv(agents_view, actor_din), rows};
+  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+  StepOut so = {action, log_prob, value, logits, forced_action};
+  // Few critic tiles (at most one per CU next to the actor's blocks): hybrid launch, cooperative critic blocks
+  {
+    const int tiles_c = mava_cdiv(critic_rows, 32);
+    int nba_h = mava_cdiv(mava_cdiv(rows, 32), 4);
+    if (nba_h > 128) nba_h = 128;
+    if (g_policy_variant == 0 && rows > 0 && critic_rows > 0 && tiles_c <= 128 && critic_din <= 287) {
+      coop::CoopTask ck = {};
+      ck.params = critic_params; ck.x = critic_input; ck.din = critic_din; ck.no = 1; ck.xshare = critic_share;
+      ck.R = critic_rows; ck.value = value; ck.vbroadcast = value_broadcast;
+      const int rc = launch_hybrid(ta, ck, nba_h, tiles_c, n_actions, action_mask, slo, shi, step, row_offset, greedy, so, s);
+      if (rc != 1) return rc;  // 1 = shape not instantiated: fall through to the per-wave launch
+    }
+  }
   FwdTask tc = {critic_params, critic_input, critic_din, 1, critic_share,
                 pick_xv(critic_input, critic_din), critic_rows};
   int nba = mava_cdiv(mava_cdiv(rows, 32), 4);
@@ -254,8 +340,6 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   if (nbc > 256) nbc = 256;
   if (nba < 1 && rows > 0) nba = 1;
   if (nbc < 1 && critic_rows > 0) nbc = 1;
-  StepOut so = {action, log_prob, value, logits, forced_action};
-  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
 #define LAUNCH_STEP(NO)                                                                         \
   do {                                                                                          \
     const size_t lb = lds_bytes<NO>() > lds_bytes<1>() ? lds_bytes<NO>() : lds_bytes<1>();      \

@@ -1,4 +1,5 @@
-"""Device time of one acting step (mava_policy_step_f32) at the BASELINE config-2 shape, per kernel variant,
+"""Device time of one acting step (mava_policy_step_f32) at the BASELINE config-2 shape, per kernel variant
+(0 = default: hybrid launch when the critic has few tiles; 1 = per-wave kernel always; 2 = cooperative kernels),
 timed through a captured HIP graph (no host launch path)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +36,7 @@ def graph_time(fn):
     return best
 
 
-for variant in (0, 2):
+for variant in (0, 1, 2):
     lib().mava_policy_set_variant(variant)
     for name, kw in (("critic per agent row", dict(critic_share=A, critic_rows=EA, value_broadcast=1)),
                      ("critic per env row", dict(critic_share=1, critic_rows=E, value_broadcast=A)),

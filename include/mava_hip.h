@@ -184,7 +184,11 @@ int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const in
                             const float* old_log_prob, const float* advantages, const double* adv_stats,
                             int n_stats, float clip_eps, float ent_coef, float* dlogits,
                             float* loss_partials, int n_blocks, mava_stream_t s);
-int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, const int32_t* idx, const float* values,
+/* agents_per_row = 1: one value per agent row (T, E, A).  agents_per_row = n > 1 (then A must be 1): the rows are
+ * (t, env) rows whose n agents share the critic input (centralised critic on a tiled global state); old_value /
+ * targets are (T, E, n) and the row's gradient is the sum of its agents' loss gradients - the same gradient as n
+ * identical network passes. */
+int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_per_row, const int32_t* idx, const float* values,
                              const float* old_value, const float* targets, float clip_eps, float vf_coef,
                              float* dvalues, float* loss_partials, int n_blocks, mava_stream_t s);
 

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
 // Sequence losses on T32 logits / values (rec_mappo.py:210-266 after the network re-unroll).
 struct SeqLossTask {
   int T, Rm, E, A, no;
+  int agg;                   // critic: agent slots per row when the rows are (t, env) rows shared by the agents (else 1)
   const int32_t* idx;
   const float* y;            // T32 (T*Rm x no) logits, or (T*Rm x 1) values
   float* dy;                 // T32 same shape
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossTask tk) {
   __shared__ float red[2][4];
   __shared__ float st[2];
   const long R = (long)tk.T * tk.Rm;
-  const float invR = 1.0f / (float)R;
+  const float invR = 1.0f / (float)(R * (ACTOR ? 1 : (tk.agg > 1 ? tk.agg : 1)));  // mean over all agent row-steps
   if (ACTOR && threadIdx.x == 0) {
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < tk.n_stats; ++i) { s1 += tk.stats[2 * i]; s2 += tk.stats[2 * i + 1]; }
@@ -339,17 +340,25 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossTask tk) {
       la += -fminf(l1, l2) * invR;
       lb += cat.entropy * invR;
     } else {
+      // one value per row; with agg > 1 the row is a (t, env) row whose agents share the critic input, and the
+      // loss gradients of its agg agent slots add up (d loss / d v = sum_a dy_a)
       const float v = tk.y[tile * 32 + jj];
-      const float ov = tk.f0[er], tg = tk.f1[er];
-      const float diff = v - ov;
-      const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
-      const float e1 = v - tg, e2 = vclip - tg;
-      const float l1 = e1 * e1, l2 = e2 * e2;
-      const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
-      const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-      const float g2 = inside ? (1.0f - g1) : 0.0f;
-      tk.dy[tile * 32 + jj] = tk.coef * (g1 * e1 + g2 * e2) * invR;
-      la += 0.5f * fmaxf(l1, l2) * invR;
+      const int na = tk.agg > 1 ? tk.agg : 1;
+      float dsum = 0.0f;
+      for (int a2 = 0; a2 < na; ++a2) {
+        const long ea = er * na + a2;
+        const float ov = tk.f0[ea], tg = tk.f1[ea];
+        const float diff = v - ov;
+        const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+        const float e1 = v - tg, e2 = vclip - tg;
+        const float l1 = e1 * e1, l2 = e2 * e2;
+        const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+        const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+        const float g2 = inside ? (1.0f - g1) : 0.0f;
+        dsum += tk.coef * (g1 * e1 + g2 * e2) * invR;
+        la += 0.5f * fmaxf(l1, l2) * invR;
+      }
+      tk.dy[tile * 32 + jj] = dsum;
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -481,15 +490,16 @@ extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_action
   return MAVA_OK;
 }
 
-extern "C" int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, const int32_t* idx, const float* values,
+extern "C" int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_per_row, const int32_t* idx, const float* values,
                                         const float* old_value, const float* targets, float clip_eps,
                                         float vf_coef, float* dvalues, float* loss_partials, int n_blocks,
                                         hipStream_t s) {
-  MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && n_blocks >= 1, 0, "mava_seq_critic_loss_f32: bad shape");
+  MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && n_blocks >= 1 && agents_per_row >= 1 && (agents_per_row == 1 || A == 1), 0,
+                 "mava_seq_critic_loss_f32: bad shape (agents_per_row > 1 needs A == 1: rows are (t, env) rows)");
   MAVA_ARG_CHECK(values && old_value && targets && dvalues && loss_partials, 1,
                  "mava_seq_critic_loss_f32: null pointer argument");
   SeqLossTask tk = {};
-  tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.no = 1; tk.idx = idx; tk.y = values; tk.dy = dvalues;
+  tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.agg = agents_per_row; tk.no = 1; tk.idx = idx; tk.y = values; tk.dy = dvalues;
   tk.f0 = old_value; tk.f1 = targets; tk.clip_eps = clip_eps; tk.coef = vf_coef; tk.loss_partials = loss_partials;
   hipLaunchKernelGGL((seq_loss_kernel<1, false>), dim3(n_blocks), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();

@@ -16,6 +16,8 @@ dense(post) -> dense(head) -> sequence loss -> dense(dpost) -> dense(dh) -> GRU 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -40,9 +42,22 @@ class _RecReplica(_Replica):
         self.done_in = torch.zeros((T, E, A), dtype=torch.uint8, device=device)  # transition.done = last_done (:136-137)
         # current hidden states in the kernels' T32 layout, and the rollout-initial copies (hstates[0], row-major)
         self.h_actor = torch.zeros(EA * H, device=device)
-        self.h_critic = torch.zeros(EA * H, device=device)
         self.h0_actor = torch.zeros((E, A, H), device=device)
-        self.h0_critic = torch.zeros((E, A, H), device=device)
+        self.set_critic_rows(A)
+
+    def set_critic_rows(self, ac: int) -> None:
+        """Critic sequences per env: A (one per agent), or 1 when the agents share the critic input and the critic
+        runs once per env (RecLearner.critic_agg)."""
+        E, dev = self.env.num_envs, self.dones.device
+        self.Ac = ac
+        # full E*A size even when only E rows are used: the buffer is swapped with the shared rollout workspace's
+        # hidden-state output every step, which the actor fills with E*A rows
+        self.h_critic = torch.zeros(E * self.env.num_agents * H, device=dev)
+        self.h0_critic = torch.zeros((E, ac, H), device=dev)
+        # per-env copies of the entering done flags and a value scratch, used by the once-per-env critic
+        self.done_env = torch.zeros((E, 1), dtype=torch.uint8, device=dev)
+        self.done_env_in = torch.zeros((self.done_in.shape[0], E, 1), dtype=torch.uint8, device=dev)
+        self.value_env = torch.zeros(E, device=dev)
 
 
 class RecLearner:
@@ -83,6 +98,17 @@ class RecLearner:
         self.Rm = self.Em * self.A
         if self.Rm % 32:
             raise ValueError(f"(num_envs / num_minibatches) * num_agents = {self.Rm} must be a multiple of 32")
+        # Centralised critic on a global state shared by the A agents of an env: identical inputs, done flags and
+        # initial hidden states give A identical hidden trajectories and values (the reference tiles the state and
+        # runs all A, networks.py:306-331).  The critic then runs ONCE per env - E sequences instead of E*A - and the
+        # sequence loss adds up the A agents' loss gradients per row (mava_seq_critic_loss_f32, agents_per_row = A).
+        self.critic_agg = bool(centralised_critic and self.critic_share == self.A and self.A > 1
+                               and self.E % 32 == 0 and self.Em % 32 == 0 and os.environ.get("MAVA_REC_CRITIC_AGG", "1") != "0")
+        self.Ac = 1 if self.critic_agg else self.A            # critic sequences per env
+        self.Rmc = self.Em * self.Ac                            # critic rows per time step of a minibatch
+        if self.critic_agg:
+            for rep in self.reps:
+                rep.set_critic_rows(1)
 
         net = config.network
         mk = lambda c: MLPTorso(**{k: v for k, v in c.items() if k != "_target_"})
@@ -152,7 +178,7 @@ class RecLearner:
         dones = st(lambda r: r.dones).bool()
         ts = TimeStep(torch.where(dones[..., 0], 2, 1).to(torch.int8), st(lambda r: r.last_reward), 1.0 - dones.float(), obs, {})
         hst = HiddenStates(st(lambda r: t32_to_rows(r.h_actor, H, E * A).view(E, A, H)),
-                           st(lambda r: t32_to_rows(r.h_critic, H, E * A).view(E, A, H)))
+                           st(lambda r: t32_to_rows(r.h_critic, H, E * self.Ac).view(E, self.Ac, H).expand(E, A, H)))
         env_state = {"step_count": st(lambda r: r.state.step_count), "episode_return": st(lambda r: r.state.ep_return),
                      "episode_length": st(lambda r: r.state.ep_length)}
         return RNNLearnerState(params, OptStates(*opts), key, env_state, ts, dones, hst)
@@ -169,9 +195,10 @@ class RecLearner:
         E, A = self.E, self.A
         EA = E * A
         ws = self.ws_roll
+        EAc = E * self.Ac
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
-            rep.h0_critic.view(EA, H).copy_(t32_to_rows(rep.h_critic, H, EA))
+            rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
         for t in range(self.T):
             step = self.t_global + t
             for u, rep in enumerate(self.reps):
@@ -184,8 +211,15 @@ class RecLearner:
                                                 step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
                                                 ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
                 # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
-                self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1, rep.h_critic, True,
-                                                     None, 1, EA, E, A, training=False, y_out=rep.value[t])
+                if self.critic_agg:  # once per env, value broadcast to the A agent slots
+                    rep.done_env.copy_(rep.dones[:, :1])
+                    rep.done_env_in[t].copy_(rep.done_env)
+                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
+                                                         rep.h_critic, True, None, 1, E, E, 1, training=False, y_out=rep.value_env)
+                    rep.value[t].copy_(rep.value_env.view(E, 1).expand(E, A))
+                else:
+                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1, rep.h_critic,
+                                                         True, None, 1, EA, E, A, training=False, y_out=rep.value[t])
                 rep.h_critic, ws.hs = ws.hs, rep.h_critic
                 rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
                                   rep.info_length[n, t], rep.info_terminal[n, t])
@@ -202,9 +236,15 @@ class RecLearner:
         E, A, T = self.E, self.A, self.T
         EA = E * A
         for rep in self.reps:
-            self.critic_network.forward_sequence(pc, self.ws_roll, self._critic_x(rep, T, T + 1), self.critic_share,
-                                                 rep.dones.view(1, E, A), rep.h_critic, True, None, 1, EA, E, A, training=False,
-                                                 y_out=rep.last_val)
+            if self.critic_agg:
+                rep.done_env.copy_(rep.dones[:, :1])
+                self.critic_network.forward_sequence(pc, self.ws_roll, self._critic_x(rep, T, T + 1), 1, rep.done_env.view(1, E, 1),
+                                                     rep.h_critic, True, None, 1, E, E, 1, training=False, y_out=rep.value_env)
+                rep.last_val.view(E, A).copy_(rep.value_env.view(E, 1).expand(E, A))
+            else:
+                self.critic_network.forward_sequence(pc, self.ws_roll, self._critic_x(rep, T, T + 1), self.critic_share,
+                                                     rep.dones.view(1, E, A), rep.h_critic, True, None, 1, EA, E, A, training=False,
+                                                     y_out=rep.last_val)
             ops.gae(rep.reward.view(T, EA), rep.value.view(T, EA), rep.done_in.view(T, EA), rep.last_val.view(EA),
                     float(s.gamma), float(s.gae_lambda), last_done=rep.dones.view(EA), out=(rep.adv.view(T, EA), rep.tgt.view(T, EA)))
 
@@ -230,12 +270,17 @@ class RecLearner:
                                                  self.g[: self.Pa], accumulate=acc)
             # ---- critic (rec_mappo.py:244-266)
             cx = self._critic_x(rep, 0, T)
-            self.critic_network.forward_sequence(pc, ws, cx, self.critic_share, rep.done_in, rep.h0_critic, False, idx, T, Rm, E, A,
+            if self.critic_agg:  # E-row sequences: kernel view (E envs x 1 "agent"), A agent slots per row in the loss
+                c_share, c_done, c_Rm, c_A, c_apr = 1, rep.done_env_in, self.Rmc, 1, A
+            else:
+                c_share, c_done, c_Rm, c_A, c_apr = self.critic_share, rep.done_in, Rm, A, 1
+            self.critic_network.forward_sequence(pc, ws, cx, c_share, c_done, rep.h0_critic, False, idx, T, c_Rm, E, c_A,
                                                  training=True)
-            check(L.mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt), float(s.clip_eps),
-                                             float(s.vf_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st), "mava_seq_critic_loss_f32")
+            check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
+                                             float(s.clip_eps), float(s.vf_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st),
+                  "mava_seq_critic_loss_f32")
             ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
-            self.critic_network.backward_sequence(pc, ws, cx, self.critic_share, rep.done_in, idx, T, Rm, E, A, self.slabs,
+            self.critic_network.backward_sequence(pc, ws, cx, c_share, c_done, idx, T, c_Rm, E, c_A, self.slabs,
                                                   self.g[self.Pa : self.P], accumulate=acc)
         parallel.allreduce_sum_(self.g)
         ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,

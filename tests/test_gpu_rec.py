@@ -204,7 +204,7 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
     fc_d = d(fc)
     critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
     ov_d, tg_d = d(old_v), d(tgt)
-    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, ptr(ws.dy),
+    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, 1, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, ptr(ws.dy),
                                          ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
     gc = torch.zeros(critic.num_params, device=dev)
     critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False)
@@ -214,16 +214,18 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
     assert_close(gc.cpu().numpy(), g, 1e-4, "recurrent critic gradient")
 
 
-@pytest.mark.parametrize("system,U", [("rec_mappo", 1), ("rec_ippo", 2)])
-def test_rec_learner_update_matches_oracle(dev, system, U):
-    """End to end: the HIP recurrent learner against the whole-update oracle on identical inputs."""
+@pytest.mark.parametrize("system,U,E", [("rec_mappo", 1, 16), ("rec_ippo", 2, 16), ("rec_mappo", 1, 64)])
+def test_rec_learner_update_matches_oracle(dev, system, U, E):
+    """End to end: the HIP recurrent learner against the whole-update oracle on identical inputs.  E = 64 switches the
+    centralised critic to one sequence per ENV (the agents share the global state; the oracle, like the reference,
+    evaluates all E*A tiled rows)."""
     from mava_amd import envs
     from mava_amd.config import compose
     from mava_amd.systems.ppo import rec_ippo, rec_mappo
     from oracle import ppo_oracle as po
     from oracle.rec_loop import OracleRecLearner
 
-    E, A, O, nA, T, K, M = 16, 4, 10, 5, 6, 2, 2
+    A, O, nA, T, K, M = 4, 10, 5, 6, 2, 2
     cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
                                         f"system.num_minibatches={M}", f"system.update_batch_size={U}"])
     cfg.env.scenario.task_config.num_agents = A
@@ -236,7 +238,9 @@ def test_rec_learner_update_matches_oracle(dev, system, U):
     env, _ = envs.make(cfg, add_global_state=central, device=dev)
     learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
     L = learn.learner
+    assert L.critic_agg == (central and E == 64)
     assert state.hstates.policy_hidden_state.shape == (1, U, E, A, 128) and state.dones.shape == (1, U, E, A)
+    assert state.hstates.critic_hidden_state.shape == (1, U, E, A, 128)
     k = state.params.actor_params["params"]["ScannedRNN_0"]["GRUCell_0"]["hz"]["kernel"]
     assert k.shape == (1, U, 128, 128)
 

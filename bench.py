@@ -182,11 +182,11 @@ def main() -> None:
                    "parallelism": f"dp{world}"},
     }
 
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_v4_pmc_traffic.json): counters
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_v5_pmc_traffic.json): counters
     # cannot be read from inside this process, so the measured figures of the same workload are attached.
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")) as f:
             traffic = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         pass

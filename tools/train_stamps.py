@@ -43,6 +43,9 @@ for which in ("critic", "actor"):
     a.record(); run(); b.record(); torch.cuda.synchronize()
     s = stamps.cpu().numpy().reshape(4, 16)
     tot = s.sum(1)
-    print(f"== {which}: launch {a.elapsed_time(b):.3f} ms, block 0 cycles per wave {tot.tolist()}, 128 tiles")
+    # row tiles per block: agent rows for the actor; (t,e) rows for the critic when the agents of a row are aggregated
+    rows = Rb * A if which == "actor" else Rb
+    ntile = -(-rows // 32 // 256)
+    print(f"== {which}: launch {a.elapsed_time(b):.3f} ms, block 0 cycles per wave {tot.tolist()}, {ntile} tiles per block")
     for i, n in enumerate(names):
-        print(f"   {n:16s} " + "  ".join(f"{s[w, i] / 128:8.0f}" for w in range(4)) + f"   ({100 * s[0, i] / tot[0]:5.1f} %)")
+        print(f"   {n:16s} " + "  ".join(f"{s[w, i] / ntile:8.0f}" for w in range(4)) + f"   ({100 * s[0, i] / tot[0]:5.1f} %)")

@@ -1,4 +1,4 @@
-"""In-tree build of libmavahip.so (hipcc, gfx950 only) and of the C oracle.
+"""In-tree build of libmavahip.so (hipcc, gfx950 only).
 
 `python -m mava_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
 Objects are rebuilt only when a source or header is newer than the object.

@@ -11,14 +11,19 @@
 // 32-row tiles of the gathered minibatch.  All products run TRANSPOSED on the exact-f32 MFMA
 // (32x32x2): out^T[feature][row] = W^T . in^T, so the batch row sits on the lane and wave w owns
 // feature tile [32w, 32w+32) of every layer:
-//   P1  z1_w  = b1 + W1[:, w]^T x^T            A: W1 from L2 (coalesced), B: x from HBM
-//   P2  z2_w  = b2 + W2[:, w]^T h1^T           A: W2 in LDS, B: h1^T in LDS; partial head logits
-//   P3  loss + dlogits on the VALU (every lane owns one row); dz2_w = (W3 dy) * relu'(z2_w)
-//   P4  dh1_w = W2[w, :] dz2^T                 A: W2 in LDS (row walk, odd stride), B: dz2^T in LDS
-//       small gradients (dW3, db3, db2) as per-thread LDS sweeps with register accumulators
-//   P5  gW2[:, w] += h1^T . dz2 ; gW1[:, w] += x^T . dz1   (A: h1^T in LDS / x from HBM)
-// The weight-gradient accumulators (KT1*16 + 64 AGPRs per lane) stay resident for the whole
-// launch; activations cross waves through four 16.5 KB LDS tiles ([feature][row], stride 33 =>
+//   P1  z1_w  = W1[:, w]^T x^T                 A: W1 from L2 through a register ring (resident up to 96 inputs),
+//                                              B: the gathered x tile in LDS (16-byte rows, ds_read_b128); the tile's
+//                                              ones column at index din multiplies "row din" of W1 = b1
+//   P2  z2_w  = b2 + W2[:, w]^T h1^T           A: W2 in LDS, B: h1^T in LDS; partial head logits as 16 more MFMAs
+//                                              (B = the layer-2 accumulator, A = W3 words in registers)
+//   P3  loss + dlogits: critic per lane (one agent of the row per (wave, half) when the agents of a (t,e) row share
+//       the input and are aggregated); actor once per row, lane-parallel (NO lanes per row, DPP reductions), dy
+//       through an LDS tile; dz2_w = (W3 dy) * relu'(z2_w) (MFMA for the actor)
+//   P4  dh1_w = W2[w, :] dz2^T                 A: W2 in LDS (row walk, odd stride), B: dz2^T in LDS;
+//       gW3^T += dy h2^T (MFMA, actor); the critic's dW3 and every bias gradient are per-lane register partials
+//   P5  gW2[:, w] += h1^T . dz2 ; gW1[:, w] += x^T . dz1   (A: h1^T / the x tile in LDS; row din of gW1 = db1)
+// The weight-gradient accumulators (KT1*16 + 64 (+16) AGPRs per lane) stay resident for the whole
+// launch; activations cross waves through three or four 16.5 KB LDS tiles ([feature][row], stride 33 =>
 // conflict-free for both the B-operand row walk and the A-operand feature walk).  Each block
 // writes ONE partial-gradient slab; mava_slab_reduce_f32 sums slabs in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).

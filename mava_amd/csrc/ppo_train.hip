@@ -100,21 +100,35 @@ TrainLdsLayout make_layout(int kt1) {
   return L;
 }
 
-// advantage statistics of one minibatch: partial (sum, sumsq) in f64 per block
+// advantage statistics of one minibatch: partial (sum, sumsq) in f64 per block.  One thread per (t,e) index b (its A
+// agent values are contiguous), four indices in flight per thread: the index gathers go out first, then the values
+// that depend on them - not one dependent idx -> value chain per element with an integer division in front.
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv,
                                                         const int32_t* __restrict__ idx,
                                                         long idx_base, int Rb, int A,
                                                         double* __restrict__ partials) {
   __shared__ double sh[2][4];
   double s1 = 0.0, s2 = 0.0;
-  const long R = (long)Rb * A;
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < R; q += (long)gridDim.x * 256) {
-    const long b = q / A;
-    const int a = (int)(q - b * A);
-    const long p = idx ? (long)idx[b] : idx_base + b;
-    const double v = (double)adv[p * A + a];
-    s1 += v;
-    s2 += v * v;
+  const long stride = (long)gridDim.x * 256;
+  for (long b0 = (long)blockIdx.x * 256 + threadIdx.x; b0 < Rb; b0 += 4 * stride) {
+    long p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long b = b0 + u * stride;
+      const long bc = b < Rb ? b : b0;
+      p[u] = idx ? (long)idx[bc] : idx_base + bc;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (b0 + u * stride < Rb) {
+        const float* row = adv + p[u] * A;
+        for (int a = 0; a < A; ++a) {
+          const double v = (double)row[a];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     s1 += __shfl_down(s1, o, 64);

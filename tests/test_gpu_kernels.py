@@ -355,10 +355,12 @@ def test_gae_variants(dev, variant, T, N, rec):
     assert_close(tgt.cpu().numpy(), want_t, 1e-5, f"tgt variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_policy_kernels_both_variants(dev, variant):
-    """The per-wave register-resident kernel (default) and the block-cooperative acting kernels agree with
-    the oracle on logits, values, log-probs and sampled actions."""
+    """The default acting step (per-wave actor; hybrid launch with block-cooperative critic blocks when the critic has
+    few tiles), the per-wave kernel alone (1) and the block-cooperative kernels (2) agree with the oracle on logits,
+    values, log-probs and sampled actions - with one critic pass per agent row and with one pass per env broadcast
+    to the agents."""
     from mava_amd import ops
     from mava_amd._lib import lib
 
@@ -377,6 +379,10 @@ def test_policy_kernels_both_variants(dev, variant):
                                                       n_actions=nA, critic_share=A, seed=99, step=5, row_offset=7,
                                                       want_logits=True)
         raw = ops.mlp_forward(_t(fc, dev), A * O, 1, _t(gs, dev), rows=rows, x_share=A)
+        # one critic pass per env, value written to all A agent slots
+        action_b, logp_b, value_b, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                                       n_actions=nA, critic_share=1, critic_rows=E, value_broadcast=A,
+                                                       seed=99, step=5, row_offset=7)
         torch.cuda.synchronize()
     finally:
         lib().mava_policy_set_variant(0)
@@ -385,6 +391,8 @@ def test_policy_kernels_both_variants(dev, variant):
     assert_close(logits.cpu().numpy(), y, 1e-5, "logits")
     assert_close(value.cpu().numpy(), np.repeat(v, A), 1e-5, "value")
     assert_close(raw.cpu().numpy()[:, 0], np.repeat(v, A), 1e-5, "raw forward")
+    assert_close(value_b.cpu().numpy(), np.repeat(v, A), 1e-5, "broadcast value")
+    assert torch.equal(action_b, action) and torch.equal(logp_b, logp)
     z = po.masked_logits(y, mask)
     u = philox.policy_uniforms(99, 5, rows, nA, row_offset=7)
     a_or = po.gumbel_argmax(z, u)

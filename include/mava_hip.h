@@ -197,6 +197,23 @@ int mava_seq_sample_f32(int rows, int n_actions, const float* logits, const uint
                         uint32_t step, uint32_t row_offset, int greedy, int32_t* action, float* log_prob,
                         mava_stream_t s);
 
+/* Fused recurrent ACTING step: rec_mappo.py:108-129 (_env_step) for both networks in one launch -
+ * pre_torso -> GRU cell with reset-on-done (networks.py:238-266) -> post_torso -> head, then mask / Gumbel-max
+ * sample / log-prob (actor; same Philox stream as mava_seq_sample_f32) or the value (critic).
+ * Parameters: the recurrent flat layout [Wpre | bpre | Wi | bi | Wh | bhn | Wpost | bpost | Whead | bhead].
+ * agents_view (rows_a, actor_din), critic_input (ceil(rows_c / critic_share), critic_din) row-major;
+ * done_* u8 flags entering the step, one per row (critic row r reads done_c[r * done_c_stride]: stride A reads the
+ * per-agent flags of an env's first agent when the critic runs once per env); h_*_in / h_*_out: T32 (rows x 128)
+ * hidden states, distinct buffers;
+ * rows_* multiples of 32 (0 skips that network); value (rows_c * value_broadcast). */
+int mava_rec_step_f32(const float* actor_params, int actor_din, int n_actions, const float* agents_view,
+                      const uint8_t* action_mask, const uint8_t* done_a, const float* h_actor_in,
+                      float* h_actor_out, int rows_a, uint64_t seed, uint32_t step, uint32_t row_offset,
+                      int greedy, int32_t* action, float* log_prob, const float* critic_params, int critic_din,
+                      const float* critic_input, int critic_share, const uint8_t* done_c, int done_c_stride,
+                      const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                      float* value, mava_stream_t s);
+
 /* T32 <-> row-major conversion of a (rows x N) matrix. */
 int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);
 

@@ -25,6 +25,7 @@ HIP_SOURCES = [
     "synth_rware.hip",
     "rec_dense.hip",
     "rec_gru.hip",
+    "rec_step.hip",
     "engine.hip",
 ]
 CPP_SOURCES = ["api.cpp"]

@@ -42,6 +42,7 @@ class _RecReplica(_Replica):
         self.done_in = torch.zeros((T, E, A), dtype=torch.uint8, device=device)  # transition.done = last_done (:136-137)
         # current hidden states in the kernels' T32 layout, and the rollout-initial copies (hstates[0], row-major)
         self.h_actor = torch.zeros(EA * H, device=device)
+        self.h_actor_next = torch.zeros_like(self.h_actor)
         self.h0_actor = torch.zeros((E, A, H), device=device)
         self.set_critic_rows(A)
 
@@ -53,6 +54,7 @@ class _RecReplica(_Replica):
         # full E*A size even when only E rows are used: the buffer is swapped with the shared rollout workspace's
         # hidden-state output every step, which the actor fills with E*A rows
         self.h_critic = torch.zeros(E * self.env.num_agents * H, device=dev)
+        self.h_critic_next = torch.zeros_like(self.h_critic)  # ping-pong partner for the fused acting step
         self.h0_critic = torch.zeros((E, ac, H), device=dev)
         # per-env copies of the entering done flags and a value scratch, used by the once-per-env critic
         self.done_env = torch.zeros((E, 1), dtype=torch.uint8, device=dev)
@@ -199,33 +201,65 @@ class RecLearner:
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
             rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
+        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0"
         for t in range(self.T):
             step = self.t_global + t
             for u, rep in enumerate(self.reps):
+                if fused:
+                    # ONE launch for both networks: pre_torso -> GRU cell -> post_torso -> head -> sample / value
+                    # (mava_rec_step_f32); the critic runs once per env when the agents share its input.  The flags
+                    # entering step t are the previous step's done flags, read in place (the once-per-env critic reads
+                    # agent 0's flag of each env: stride A); done_in is materialised once after the rollout.
+                    agg = self.critic_agg
+                    d_prev = rep.dones if t == 0 else rep.done[t - 1]
+                    check(lib().mava_rec_step_f32(
+                        ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(rep.action_mask[t]), ptr(d_prev),
+                        ptr(rep.h_actor), ptr(rep.h_actor_next), EA, self.seed & (2**64 - 1), step & 0xFFFFFFFF,
+                        ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]), ptr(rep.log_prob[t]),
+                        ptr(pc), self.Oc, ptr(self._critic_x(rep, t, t + 1)), 1 if agg else self.critic_share,
+                        ptr(d_prev), A if agg else 1, ptr(rep.h_critic), ptr(rep.h_critic_next),
+                        E if agg else EA, A if agg else 1, ptr(rep.value[t]), stream_ptr()), "mava_rec_step_f32")
+                    rep.h_actor, rep.h_actor_next = rep.h_actor_next, rep.h_actor
+                    rep.h_critic, rep.h_critic_next = rep.h_critic_next, rep.h_critic
+                    rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
+                                      rep.info_length[n, t], rep.info_terminal[n, t])
+                    continue
                 rep.done_in[t].copy_(rep.dones)
                 d1 = rep.done_in[t : t + 1]
-                self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E, A,
-                                                    training=False)
-                rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
-                check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
-                                                step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
-                                                ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
-                # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
-                if self.critic_agg:  # once per env, value broadcast to the A agent slots
+                if self.critic_agg:
                     rep.done_env.copy_(rep.dones[:, :1])
                     rep.done_env_in[t].copy_(rep.done_env)
-                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
-                                                         rep.h_critic, True, None, 1, E, E, 1, training=False, y_out=rep.value_env)
-                    rep.value[t].copy_(rep.value_env.view(E, 1).expand(E, A))
-                else:
-                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1, rep.h_critic,
-                                                         True, None, 1, EA, E, A, training=False, y_out=rep.value[t])
-                rep.h_critic, ws.hs = ws.hs, rep.h_critic
+                if True:
+                    self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E,
+                                                        A, training=False)
+                    rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
+                    check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
+                                                    step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
+                                                    ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
+                    # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
+                    if self.critic_agg:  # once per env, value broadcast to the A agent slots
+                        self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
+                                                             rep.h_critic, True, None, 1, E, E, 1, training=False,
+                                                             y_out=rep.value_env)
+                        rep.value[t].copy_(rep.value_env.view(E, 1).expand(E, A))
+                    else:
+                        self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1,
+                                                             rep.h_critic, True, None, 1, EA, E, A, training=False,
+                                                             y_out=rep.value[t])
+                    rep.h_critic, ws.hs = ws.hs, rep.h_critic
                 rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
                                   rep.info_length[n, t], rep.info_terminal[n, t])
                 rep.dones.copy_(rep.done[t])
                 if t == self.T - 1:
                     rep.last_reward.copy_(rep.reward[t])
+        if fused:
+            for rep in self.reps:  # transition.done = the flag entering each step (rec_mappo.py:136-137), in two copies
+                rep.done_in[0].copy_(rep.dones)
+                rep.done_in[1:].copy_(rep.done[: self.T - 1])
+                rep.dones.copy_(rep.done[self.T - 1])
+                rep.last_reward.copy_(rep.reward[self.T - 1])
+                if self.critic_agg:
+                    rep.done_env_in.copy_(rep.done_in[:, :, :1])
         self.t_global += self.T
 
     def _bootstrap_and_gae(self) -> None:

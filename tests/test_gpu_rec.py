@@ -368,3 +368,61 @@ def test_rec_learner_adopts_foreign_params(dev):
     assert torch.equal(L.p[: L.Pa].cpu(), fa) and torch.equal(L.p[L.Pa :].cpu(), fc)
     assert torch.equal(state.params.actor_params["params"]["pre_torso"]["Dense_0"]["kernel"][0, 0].cpu(),
                        fa[: L.Oa * 128].view(L.Oa, 128))  # the state's trees are views of the adopted buffers
+
+
+@pytest.mark.parametrize("E,A,din,S,nA,share", [(16, 4, 37, 23, 6, False), (32, 8, 155, 188, 13, True), (8, 4, 20, 20, 20, False)])
+def test_fused_rec_step_matches_oracle(dev, E, A, din, S, nA, share):
+    """mava_rec_step_f32 (one launch: both networks, GRU cell with reset, head, sampling) against the oracle's recurrent
+    forward for one step, and its sampled actions against mava_seq_sample_f32 on the oracle-checked logits path."""
+    from mava_amd._lib import check, lib, ptr, stream_ptr
+    from mava_amd.networks import DiscreteActionHead, MLPTorso
+    from mava_amd.rec_networks import RecurrentActor, rows_to_t32, t32_to_rows
+
+    rng = np.random.default_rng(E + din)
+    R = E * A
+    Rc = E if share else R                      # critic rows: one per env when the agents share its input
+    fa = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
+    fc = ro.init_rec(rng, S, 1, 1.0).astype(np.float32)
+    for f, d in ((fa, din), (fc, S)):           # non-zero biases everywhere
+        f[d * 128 : d * 128 + 128] = rng.standard_normal(128) * 0.1
+    x = rng.standard_normal((R, din)).astype(np.float32)
+    xc = rng.standard_normal((Rc, S)).astype(np.float32)
+    mask = rng.random((R, nA)) > 0.3
+    mask[:, 0] = True
+    done_a = rng.random(R) < 0.3
+    done_c = rng.random(Rc) < 0.3
+    ha = rng.standard_normal((R, 128)).astype(np.float32)
+    hc = rng.standard_normal((Rc, 128)).astype(np.float32)
+    pad = lambda a, n: np.concatenate([a, np.zeros((n - a.shape[0],) + a.shape[1:], a.dtype)])  # rows up to a multiple of 32
+    Rp, Rcp = -(-R // 32) * 32, -(-Rc // 32) * 32
+    xa_d, xc_d = _t(pad(x, Rp), dev), _t(pad(xc, Rcp), dev)
+    mask_d = _t(pad(mask, Rp), dev).view(torch.uint8)
+    da_d, dc_d = _t(pad(done_a, Rp), dev).view(torch.uint8), _t(pad(done_c, Rcp), dev).view(torch.uint8)
+    ha_in, hc_in = rows_to_t32(_t(pad(ha, Rp), dev)), rows_to_t32(_t(pad(hc, Rcp), dev))
+    ha_out, hc_out = torch.zeros_like(ha_in), torch.zeros_like(hc_in)
+    action = torch.zeros(Rp, dtype=torch.int32, device=dev)
+    logp = torch.zeros(Rp, device=dev)
+    vb = A if share else 1
+    value = torch.zeros(Rcp * vb, device=dev)
+    fa_d, fc_d = _t(fa, dev), _t(fc, dev)
+    check(lib().mava_rec_step_f32(ptr(fa_d), din, nA, ptr(xa_d), ptr(mask_d), ptr(da_d), ptr(ha_in), ptr(ha_out), Rp, 77, 5, 11, 0,
+                                  ptr(action), ptr(logp), ptr(fc_d), S, ptr(xc_d), 1, ptr(dc_d), 1, ptr(hc_in), ptr(hc_out), Rcp, vb,
+                                  ptr(value), stream_ptr()), "mava_rec_step_f32")
+    torch.cuda.synchronize()
+    ya, _, ha_new = ro.rec_forward(fa, din, nA, x[None], done_a[None], ha)
+    yc, _, hc_new = ro.rec_forward(fc, S, 1, xc[None], done_c[None], hc)
+    assert_close(t32_to_rows(ha_out, 128, Rp).cpu().numpy()[:R], ha_new, 1e-5, "actor hidden state")
+    assert_close(t32_to_rows(hc_out, 128, Rcp).cpu().numpy()[:Rc], hc_new, 1e-5, "critic hidden state")
+    assert_close(value.cpu().numpy().reshape(Rcp, vb)[:Rc], np.repeat(yc[0], vb, 1), 1e-5, "value")
+    # sampling: the same Philox stream as mava_seq_sample_f32, fed with the oracle's logits
+    logits_t32 = rows_to_t32(_t(pad(ya[0].astype(np.float32), Rp), dev))
+    a2 = torch.zeros(Rp, dtype=torch.int32, device=dev)
+    lp2 = torch.zeros(Rp, device=dev)
+    check(lib().mava_seq_sample_f32(Rp, nA, ptr(logits_t32), ptr(mask_d), 77, 5, 11, 0, ptr(a2), ptr(lp2), stream_ptr()), "sample")
+    torch.cuda.synchronize()
+    a, a2 = action.cpu().numpy()[:R], a2.cpu().numpy()[:R]
+    assert (a != a2).mean() < 0.02  # f32 logits vs f64-derived logits: near-ties of the Gumbel scores only
+    assert mask[np.arange(R), a].all(), "sampled an illegal action"
+    z = np.where(mask, ya[0], np.finfo(np.float32).min)
+    lsm = z - np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)) - z.max(-1, keepdims=True)
+    assert_close(logp.cpu().numpy()[:R], lsm[np.arange(R), a], 1e-5, "log_prob")

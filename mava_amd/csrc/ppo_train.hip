@@ -847,8 +847,12 @@ int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
   MAVA_ARG_CHECK(lb <= 163840, 8,
                  "ppo_train: %zu bytes of LDS needed (n_out pad %d, input width %d) exceed the 160 KiB of a CU",
                  lb, NO, tk.din);
-  MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR, XV>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+  static bool attr_set = false;  // once per instantiation (lb is a function of the template arguments only)
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR, XV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+    attr_set = true;
+  }
   hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR, XV>), dim3(n_slab), dim3(256), lb, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;

@@ -459,9 +459,12 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
 template <int NB, int NTW, bool RM, bool FULLK>
 int launch_dense_rm(const DenseTask& tk, hipStream_t s) {
   const size_t lb = RM ? ((size_t)32 * (16 * NB + 1) + 4) * sizeof(float) : 0;
-  if (lb > 0)
+  static bool attr_set = false;  // once per instantiation
+  if (lb > 0 && !attr_set) {
     MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_kernel<NB, NTW, RM, FULLK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+    attr_set = true;
+  }
   int blocks = tk.rows / 32;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL((rec_dense_kernel<NB, NTW, RM, FULLK>), dim3(blocks), dim3(256), lb, s, tk);
@@ -488,8 +491,12 @@ int launch_xty(const XtyTask& tk, int n_slab, hipStream_t s) {
   const int npad = ((tk.N + 31) / 32) * 32;
   const size_t lb = (size_t)(32 * KT + npad) * 33 * sizeof(float);
   MAVA_ARG_CHECK(lb <= 163840, 8, "mava_rec_xty_f32: %zu bytes of LDS needed", lb);
-  MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_xty_kernel<KT, NTW>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+  static bool attr_set = false;  // once per instantiation: allow the whole 160 KiB (lb varies with N)
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_xty_kernel<KT, NTW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
   hipLaunchKernelGGL((rec_xty_kernel<KT, NTW>), dim3(n_slab), dim3(256), lb, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;

@@ -229,24 +229,24 @@ class RecLearner:
                 if self.critic_agg:
                     rep.done_env.copy_(rep.dones[:, :1])
                     rep.done_env_in[t].copy_(rep.done_env)
-                if True:
-                    self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E,
-                                                        A, training=False)
-                    rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
-                    check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
-                                                    step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
-                                                    ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
-                    # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
-                    if self.critic_agg:  # once per env, value broadcast to the A agent slots
-                        self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
-                                                             rep.h_critic, True, None, 1, E, E, 1, training=False,
-                                                             y_out=rep.value_env)
-                        rep.value[t].copy_(rep.value_env.view(E, 1).expand(E, A))
-                    else:
-                        self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1,
-                                                             rep.h_critic, True, None, 1, EA, E, A, training=False,
-                                                             y_out=rep.value[t])
-                    rep.h_critic, ws.hs = ws.hs, rep.h_critic
+                # layer-wise acting step (MAVA_REC_FUSED_STEP=0): the training kernels with T = 1
+                self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E,
+                                                    A, training=False)
+                rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
+                check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
+                                                step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
+                                                ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
+                # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
+                if self.critic_agg:  # once per env, value broadcast to the A agent slots
+                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
+                                                         rep.h_critic, True, None, 1, E, E, 1, training=False,
+                                                         y_out=rep.value_env)
+                    rep.value[t].copy_(rep.value_env.view(E, 1).expand(E, A))
+                else:
+                    self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1,
+                                                         rep.h_critic, True, None, 1, EA, E, A, training=False,
+                                                         y_out=rep.value[t])
+                rep.h_critic, ws.hs = ws.hs, rep.h_critic
                 rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
                                   rep.info_length[n, t], rep.info_terminal[n, t])
                 rep.dones.copy_(rep.done[t])

@@ -42,6 +42,14 @@ def _tree_to(tree: Any, device) -> Any:
     return tree
 
 
+def _tree_clone(tree: Any) -> Any:
+    if isinstance(tree, torch.Tensor):
+        return tree.clone()
+    if isinstance(tree, dict):
+        return {k: _tree_clone(v) for k, v in tree.items()}
+    return copy.deepcopy(tree)
+
+
 def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable, add_global_state: bool,
                    log: Optional[Callable[[Dict[str, Any]], None]] = None, recurrent: bool = False) -> float:
     config = copy.deepcopy(_config)
@@ -91,11 +99,20 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
         restored_params = _tree_to(restored_params, eval_env.device)  # checkpoints hold host tensors
         learner_state = learner_state._replace(params=restored_params)  # learn() adopts trees that do not alias its buffers
 
+    # Logging (ff_mappo.py:476-480): the MavaLogger of the configuration (console / marl-eval JSON) on rank 0, unless
+    # the caller takes the per-evaluation records itself through `log`.
+    from ...utils.logger import LogEvent, MavaLogger
+
+    logger = MavaLogger(config) if (log is None and rank == 0) else None
+
     def emit(rec: Dict[str, Any]) -> None:
-        if rank == 0:
-            (log or (lambda r: print(json.dumps(r), flush=True)))(rec)
+        if rank == 0 and log is not None:
+            log(rec)
 
     eval_return = 0.0
+    max_episode_return = -float("inf")
+    best_params = None
+    t = 0
     for eval_step in range(int(config.arch.num_evaluation)):
         torch.cuda.synchronize()
         start = time.time()
@@ -104,21 +121,44 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
         elapsed = time.time() - start
         t = int(steps_per_rollout * (eval_step + 1))
         ep_metrics, ep_completed = get_final_step_metrics(out.episode_metrics)
-        rec: Dict[str, Any] = {"timestep": t, "steps_per_second": steps_per_rollout / elapsed}
+        ep_metrics = dict(ep_metrics)
+        ep_metrics["steps_per_second"] = steps_per_rollout / elapsed
+        rec: Dict[str, Any] = {"timestep": t, "steps_per_second": ep_metrics["steps_per_second"]}
         if ep_completed:
             rec["episode_return"] = float(ep_metrics["episode_return"].float().mean())
             rec["episode_length"] = float(ep_metrics["episode_length"].float().mean())
         for k, v in out.train_metrics.items():
             rec[k] = float(v.float().mean())  # TRAIN metrics are mean-reduced (mava/utils/logger.py:72-74)
-        # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:513 vs :535)
+        if logger is not None:  # separately: timestep, acting metrics, training metrics (ff_mappo.py:509-513)
+            logger.log({"timestep": t}, t, eval_step, LogEvent.MISC)
+            if ep_completed:
+                logger.log(ep_metrics, t, eval_step, LogEvent.ACT)
+            logger.log(out.train_metrics, t, eval_step, LogEvent.TRAIN)
+        # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:516 vs :541)
         trained_params = learner_state.params.actor_params
         eval_metrics = evaluator(trained_params, key_e + eval_step, init_act_state)
+        if logger is not None:
+            logger.log(eval_metrics, t, eval_step, LogEvent.EVAL)
         eval_return = float(eval_metrics["episode_return"].float().mean())
         rec["eval_episode_return"] = eval_return
         emit(rec)
+        if bool(config.arch.absolute_metric) and max_episode_return <= eval_return:
+            # copy.deepcopy(trained_params), ff_mappo.py:537-539: the trees are views of buffers learn() updates in place
+            best_params = _tree_clone(trained_params)
+            max_episode_return = eval_return
         learner_state = out.learner_state
         if checkpointer is not None:
             # unreplicate_n_dims (jax_utils.py:52-59): drop the (device, update_batch) leading dims of the leaves
             unrep = _unreplicate_n_dims(learner_state)
             checkpointer.save(timestep=t, unreplicated_learner_state=unrep, episode_return=eval_return)
+
+    # Measure the absolute metric (ff_mappo.py:546-553): the best parameters, 10x the evaluation episodes
+    if bool(config.arch.absolute_metric) and best_params is not None:
+        abs_evaluator = get_eval_fn(eval_env, act_fn, config, absolute_metric=True)
+        abs_metrics = abs_evaluator(best_params, key, init_act_state)
+        if logger is not None:
+            logger.log(abs_metrics, t, int(config.arch.num_evaluation) - 1, LogEvent.ABSOLUTE)
+        emit({"timestep": t, "absolute_episode_return": float(abs_metrics["episode_return"].float().mean())})
+    if logger is not None:
+        logger.stop()
     return eval_return

@@ -170,9 +170,13 @@ def test_run_experiment_with_eval_and_checkpoint(dev, system, tmp_path, monkeypa
     cfg.env.kwargs.time_limit = 12  # short evaluation episodes
     cfg.logger.checkpointing.save_model = True
     cfg.logger.checkpointing.save_args.checkpoint_uid = "t"
+    cfg.arch.num_absolute_metric_eval_episodes = 64
     recs = []
     mod.run_experiment(cfg, log=recs.append)
+    absolute = [r for r in recs if "absolute_episode_return" in r]
+    recs = [r for r in recs if "total_loss" in r]
     assert len(recs) == 2 and recs[1]["timestep"] == 2 * recs[0]["timestep"]
+    assert len(absolute) == 1 and np.isfinite(absolute[0]["absolute_episode_return"])  # ff_mappo.py:546-553
     for r in recs:
         assert r["steps_per_second"] > 0 and np.isfinite(r["total_loss"]) and np.isfinite(r["eval_episode_return"])
     ck = Checkpointer(model_name=system, checkpoint_uid="t")
@@ -188,6 +192,17 @@ def test_run_experiment_with_eval_and_checkpoint(dev, system, tmp_path, monkeypa
     cfg2.env.kwargs.time_limit = 12
     cfg2.logger.checkpointing.load_model = True
     cfg2.logger.checkpointing.load_args.checkpoint_uid = "t"
-    recs2 = []
-    mod.run_experiment(cfg2, log=recs2.append)
-    assert len(recs2) == 1 and np.isfinite(recs2[0]["total_loss"])
+    cfg2.arch.num_absolute_metric_eval_episodes = 32
+    # this run logs through the configuration's MavaLogger (marl-eval JSON writer) instead of a callback
+    cfg2.logger.use_json, cfg2.logger.use_console = True, False
+    cfg2.logger.base_exp_path = str(tmp_path / "results")
+    cfg2.logger.kwargs.json_path = "run"
+    mod.run_experiment(cfg2)
+    import json as _json
+
+    with open(tmp_path / "results" / "json" / "run" / "metrics.json") as f:
+        data = _json.load(f)
+    run = data[str(cfg2.env.env_name)][str(cfg2.env.scenario.task_name)][system]["seed_42"]
+    assert run["step_0"]["step_count"] > 0 and len(run["step_0"]["mean_episode_return"]) == 1
+    assert "steps_per_second" not in run["step_0"] or run["step_0"]["steps_per_second"][0] > 0
+    assert len(run["absolute_metrics"]["mean_episode_return"]) == 1

@@ -715,9 +715,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       }
     }
     STAMP(4);
-    __syncthreads();  // D
 
     // ---------------------------------------------------------------- P5: weight gradients
+    // gW2 needs h1^T and dz2^T only, so it runs BEFORE barrier D: the dz1^T writes above drain under its MFMAs
+    // instead of in front of the barrier
     {
       // gW2[k_in tile t][n = 32w + j] += sum_rows h1^T[k_in][row] * dz2^T[n][row]
       const float* ea = H1T + j * LDT + h;
@@ -733,6 +734,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       }
     }
     STAMP(5);
+    __syncthreads();  // D: dz1^T complete
     {
       // gW1[k_in tile t][n] += sum_rows x[row][k_in] * dz1^T[n][row];  A from the staged x tile
       const float* eb = DZ1T + (32 * w + j) * LDT + h;

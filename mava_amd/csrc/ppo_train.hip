@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       H1T[(fbase + (r & 3) + 8 * (r >> 2)) * LDT + j] = h1[r];
     }
     STAMP(0);
-    __syncthreads();  // A
     STAMP(13);
     // Next tile's gathers are issued only now: vmcnt retires in order, so issuing them before P1 would
-    // put the HBM gather latency in front of every W1 operand wait of P1.
+    // put the HBM gather latency in front of every W1 operand wait of P1.  They do not depend on the h1^T tile, so
+    // they go out BEFORE barrier A and the tile's LDS writes drain under them.
     if (have_next) {
       // idx values were gathered one iteration ago (complete by now); only now are they used
       stage_issue(xrow_next, xr);  // global -> registers, committed after barrier E
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
         for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
       }
     }
+    __syncthreads();  // A: h1^T complete
     STAMP(10);
 
     // ---------------------------------------------------------------- P2: layer 2, tile w

@@ -81,13 +81,15 @@ int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x
  * Philox4x32-10 keyed by seed with counter (row_offset + row, step, word-group, "POLI").
  * forced_action (rows) i32 or NULL: score these actions instead of sampling.
  * logits (rows, n_actions) or NULL: raw (unmasked) logits out.
+ * step_base (device, or NULL): a word added to `step` on the device, so that a captured HIP graph of a whole rollout
+ * replays with the next counters (mava_synth_rware_step takes t_base likewise).
  * rows == 0 or critic_rows == 0 skips that half (its pointers may then be NULL): the learner runs the actor
  * half on the acting stream and the value half (mava_mlp_forward_f32) on a side stream. */
 int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
                          const float* agents_view, const uint8_t* action_mask,
                          const float* critic_params, int critic_din, const float* critic_input,
                          int critic_share, int critic_rows, int value_broadcast, int rows,
-                         uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                         uint64_t seed, uint32_t step, const uint32_t* step_base, uint32_t row_offset, int greedy,
                          const int32_t* forced_action, int32_t* action, float* log_prob,
                          float* value, float* logits, mava_stream_t s);
 
@@ -137,7 +139,7 @@ int mava_ppo_set_critic_aggregation(int on);
  * action_mask (E,A,n_actions) u8, obs_step_count (E,A) i32; transition: reward (E,A) f32,
  * done (E,A) u8, info_return (E) f32, info_length (E) i32, info_terminal (E) u8. */
 int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int state_dim, int time_limit,
-                          uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
+                          uint64_t seed, uint32_t t, const uint32_t* t_base, uint32_t env_offset, int is_reset,
                           int32_t* step_count, float* run_return, int32_t* run_length,
                           float* ep_return, int32_t* ep_length, float* agents_view,
                           float* global_state, uint8_t* action_mask, int32_t* obs_step_count,

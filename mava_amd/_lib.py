@@ -42,14 +42,14 @@ _SIGNATURES = {
     "mava_slab_reduce2_f32": [vp, i32, lng, i32, vp, i32, vp, i32, vp],
     "mava_mlp_param_count": [i32, i32],
     "mava_mlp_forward_f32": [vp, i32, i32, vp, i32, i32, vp, vp],
-    "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, u32, i32,
+    "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
                              vp, vp, vp, vp, vp, vp],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
-    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, u32, i32] + [vp] * 15,
+    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 15,
     "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
     "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
     "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],

@@ -52,12 +52,12 @@ int dispatch_coop(const CoopTask& tk, hipStream_t s) {
 
 // Internal entry points used by mava_policy_step_f32 / mava_mlp_forward_f32 (mlp_policy.hip).
 int mava_coop_actor(const float* params, int din, int n_actions, const float* agents_view, const uint8_t* mask,
-                    int rows, uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                    int rows, uint64_t seed, uint32_t step, const uint32_t* step_base, uint32_t row_offset, int greedy,
                     const int32_t* forced_action, int32_t* action, float* log_prob, float* logits, hipStream_t s) {
   CoopTask tk = {};
   tk.params = params; tk.x = agents_view; tk.din = din; tk.no = n_actions; tk.xshare = 1; tk.R = rows;
   tk.mask = mask; tk.forced_action = forced_action; tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32);
-  tk.step = step; tk.row_offset = row_offset; tk.greedy = greedy; tk.action = action; tk.log_prob = log_prob;
+  tk.step = step; tk.step_base = step_base; tk.row_offset = row_offset; tk.greedy = greedy; tk.action = action; tk.log_prob = log_prob;
   tk.logits = logits;
   if (n_actions <= 8) return dispatch_coop<8, MODE_SAMPLE>(tk, s);
   if (n_actions <= 16) return dispatch_coop<16, MODE_SAMPLE>(tk, s);

@@ -16,6 +16,7 @@ struct CoopTask {
   const uint8_t* mask;          // (R, no) or null
   const int32_t* forced_action; // (R) or null
   uint32_t seed_lo, seed_hi, step, row_offset;
+  const uint32_t* step_base;    // optional device word added to step
   int greedy;
   int32_t* action;    // (R)
   float* log_prob;    // (R)
@@ -220,7 +221,8 @@ __device__ __forceinline__ void coop_body(const CoopTask& tk, const CoopLds& L, 
           const uint32_t gid = tk.row_offset + (uint32_t)row;
 #pragma unroll
           for (int c = 0; c < (NO + 3) / 4; ++c) {
-            Philox4 rnd = philox4x32_10(gid, tk.step, (uint32_t)c, 0x504f4c49u /*"POLI"*/, tk.seed_lo, tk.seed_hi);
+            Philox4 rnd = philox4x32_10(gid, tk.step + (tk.step_base ? *tk.step_base : 0u), (uint32_t)c,
+                                        0x504f4c49u /*"POLI"*/, tk.seed_lo, tk.seed_hi);
             const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

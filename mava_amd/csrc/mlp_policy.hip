@@ -70,6 +70,7 @@ struct StepOut {
   float* value;         // (R_critic * vbroadcast)
   float* logits;        // optional (R, no) raw (unmasked) logits, for parity tests
   const int32_t* forced_action;  // optional: evaluate log_prob of given actions instead of sampling
+  const uint32_t* step_base;     // optional device word added to `step` (captured HIP graphs replay with a moving counter)
 };
 
 // Per-wave actor: block `bid` of the `nblk` actor blocks; each wave carries whole 32-row tiles through the three
@@ -79,6 +80,7 @@ __device__ __forceinline__ void actor_step_body(const FwdTask& actor, float* lds
                                                 const uint8_t* __restrict__ mask, uint32_t seed_lo, uint32_t seed_hi,
                                                 uint32_t step, uint32_t row_offset, int greedy, const StepOut& out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
+  step += out.step_base ? *out.step_base : 0u;
   mlp_fill_lds<NOA>(lds, actor.params, actor.din, actor.no, 256);
   __syncthreads();
   const int ntiles = (actor.R + 31) / 32;
@@ -236,7 +238,7 @@ int launch_hybrid(const FwdTask& ta, const coop::CoopTask& ck, int nba, int nbc,
 
 // block-cooperative kernels (mlp_coop.hip)
 int mava_coop_actor(const float* params, int din, int n_actions, const float* agents_view, const uint8_t* mask,
-                    int rows, uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                    int rows, uint64_t seed, uint32_t step, const uint32_t* step_base, uint32_t row_offset, int greedy,
                     const int32_t* forced_action, int32_t* action, float* log_prob, float* logits, hipStream_t s);
 int mava_coop_value(const float* params, int din, const float* x, int x_share, int rows, int vbroadcast, float* value,
                     hipStream_t s);
@@ -292,7 +294,7 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
                                     const float* agents_view, const uint8_t* action_mask,
                                     const float* critic_params, int critic_din,
                                     const float* critic_input, int critic_share, int critic_rows,
-                                    int value_broadcast, int rows, uint64_t seed, uint32_t step,
+                                    int value_broadcast, int rows, uint64_t seed, uint32_t step, const uint32_t* step_base,
                                     uint32_t row_offset, int greedy, const int32_t* forced_action,
                                     int32_t* action, float* log_prob, float* value, float* logits,
                                     hipStream_t s) {
@@ -309,7 +311,7 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   if (g_policy_variant == 2 && actor_din <= 288 && critic_din <= 288) {
     int rc = MAVA_OK;
     if (rows > 0)
-      rc = mava_coop_actor(actor_params, actor_din, n_actions, agents_view, action_mask, rows, seed, step, row_offset,
+      rc = mava_coop_actor(actor_params, actor_din, n_actions, agents_view, action_mask, rows, seed, step, step_base, row_offset,
                            greedy, forced_action, action, log_prob, logits, s);
     if (rc != MAVA_OK) return rc;
     if (critic_rows > 0)
@@ -318,7 +320,7 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   }
   FwdTask ta = {actor_params, agents_view, actor_din, n_actions, 1, pick_xv(agents_view, actor_din), rows};
   const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
-  StepOut so = {action, log_prob, value, logits, forced_action};
+  StepOut so = {action, log_prob, value, logits, forced_action, step_base};
   // Few critic tiles (at most one per CU next to the actor's blocks): hybrid launch, cooperative critic blocks
   {
     const int tiles_c = mava_cdiv(critic_rows, 32);

@@ -30,6 +30,7 @@ struct SynthArgs {
   int time_limit;
   uint32_t seed_lo, seed_hi;
   uint32_t t;         // global step counter (unique per call)
+  const uint32_t* t_base;  // optional device word added to t (captured HIP graphs replay with a moving counter)
   uint32_t env_offset;  // global id of env 0 (rank / replica offset)
   // state: step_count (E, A) - one private copy per agent thread (no cross-thread hazard); rest (E)
   int32_t* step_count;
@@ -68,6 +69,7 @@ __device__ __forceinline__ void store_run(float* dst, const float (&v)[16], int 
 }
 
 __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
+  a.t += a.t_base ? *a.t_base : 0u;
   const uint32_t E = a.E, A = a.A, O = a.O, W = A + O;
   const uint32_t nch = max(1u, (O - 2 + 15) / 16);        // bit chunks per raw view (>= 1: chunk 0 also writes id + coordinates)
   const uint32_t n_view = E * A * nch;                    // (entity, chunk) threads
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
 }  // namespace
 
 extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int state_dim, int time_limit,
-                                     uint64_t seed, uint32_t t, uint32_t env_offset, int is_reset,
+                                     uint64_t seed, uint32_t t, const uint32_t* t_base, uint32_t env_offset, int is_reset,
                                      int32_t* step_count, float* run_return, int32_t* run_length,
                                      float* ep_return, int32_t* ep_length, float* agents_view,
                                      float* global_state, uint8_t* action_mask,
@@ -190,7 +192,7 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
                  "mava_synth_rware_step: null transition pointer");
   SynthArgs a;
   a.E = E; a.A = A; a.O = O; a.nA = n_actions; a.gs_tiles = gs_tiles; a.S = state_dim; a.time_limit = time_limit;
-  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.t = t; a.env_offset = env_offset;
+  a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.t = t; a.t_base = t_base; a.env_offset = env_offset;
   a.step_count = step_count; a.run_return = run_return; a.run_length = run_length;
   a.ep_return = ep_return; a.ep_length = ep_length; a.agents_view = agents_view;
   a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;

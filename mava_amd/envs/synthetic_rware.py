@@ -88,13 +88,16 @@ class SyntheticRware:
 
     # ---- kernel call ----------------------------------------------------------------------
     def step_into(self, state: SynthState, t: int, obs: Dict[str, torch.Tensor], reward=None, done=None, info_return=None,
-                  info_length=None, info_terminal=None, is_reset: bool = False, env_offset: Optional[int] = None) -> None:
+                  info_length=None, info_terminal=None, is_reset: bool = False, env_offset: Optional[int] = None,
+                  t_base: Optional[torch.Tensor] = None) -> None:
         """One vectorised step (or reset) writing the next observation into `obs` and the transition
-        into the given (E, A) / (E,) slots.  `t` is the replica's global step index (Philox counter)."""
+        into the given (E, A) / (E,) slots.  `t` is the replica's global step index (Philox counter); `t_base`
+        (a device int32 word) is added to it on the device, for rollouts replayed from a captured graph."""
         off = self.env_offset if env_offset is None else env_offset
         check(
             lib().mava_synth_rware_step(self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.gs_tiles,
-                                        self.synth_state_dim, self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, off & 0xFFFFFFFF,
+                                        self.synth_state_dim, self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, ptr(t_base),
+                                        off & 0xFFFFFFFF,
                                         int(is_reset), ptr(state.step_count), ptr(state.run_return), ptr(state.run_length),
                                         ptr(state.ep_return), ptr(state.ep_length), ptr(obs["agents_view"]),
                                         ptr(obs["global_state"]), ptr(obs["action_mask"]), ptr(obs["step_count"]),

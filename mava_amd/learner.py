@@ -24,6 +24,7 @@ gradient is summed with one all-reduce per minibatch (ff_mappo.py:224-238 pmean 
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -131,6 +132,12 @@ class FFLearner:
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
         self.perm_gen = torch.Generator(device=d)
         self.t_global = 0  # env steps taken per env so far (Philox step counter)
+        # the same counter on the device: the kernels add it to their relative step, so a rollout captured in a HIP
+        # graph replays with the next counters
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=d)
+        self.graph_rollout = os.environ.get("MAVA_GRAPH_ROLLOUT", "1") != "0"
+        self._graphs: Dict[Tuple[int, int], Any] = {}
+        self._graph_seen: set = set()
         self.seed = int(s.seed)
         self.timers: Optional[Dict[str, list]] = None  # bench.py: name -> [(start_event, end_event)]
 
@@ -157,6 +164,7 @@ class FFLearner:
         for rep in self.reps:
             rep.env.step_into(rep.state, 0, rep.obs_slot(0), is_reset=True)
         self.t_global = 0
+        self.step_dev.zero_()
         self.perm_gen.manual_seed(self.seed)
 
     # ---------------------------------------------------------------------------- state <-> views
@@ -219,11 +227,35 @@ class FFLearner:
 
     # ------------------------------------------------------------------------------------ update
     def _rollout(self, n: int) -> None:
+        """The launch-bound part of an update (2*T + 3 small kernels per replica): rollout, bootstrap value and GAE.
+        The first call for an `n` runs eagerly, the second is captured into a HIP graph, later ones replay it -
+        the kernels read the moving step counter from step_dev, everything else they touch is persistent."""
+        if not self.graph_rollout or self.timers is not None:
+            self._rollout_body(n)
+            self._bootstrap_and_gae()
+        else:
+            key = (n, self.seed)
+            graph = self._graphs.get(key)
+            if graph is None and key in self._graph_seen:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._rollout_body(n)
+                    self._bootstrap_and_gae()
+                self._graphs[key] = graph
+            if graph is None:
+                self._graph_seen.add(key)
+                self._rollout_body(n)
+                self._bootstrap_and_gae()
+            else:
+                graph.replay()
+        self.t_global += self.T
+
+    def _rollout_body(self, n: int) -> None:
         """ff_mappo.py:76-106: T acting steps, recording the time-major trajectory in place."""
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         EA = self.E * self.A
         for t in range(self.T):
-            step = self.t_global + t
+            step = t  # relative; the kernels add step_dev (= t_global at the start of this rollout)
             for u, rep in enumerate(self.reps):
                 av = rep.agents_view[t].view(EA, self.Oa)
                 if self.centralised:
@@ -236,15 +268,15 @@ class FFLearner:
                 self._timed("policy_step", ops.policy_step, pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
                                 critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
                                 value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
-                                row_offset=(self.rank * self.U + u) * EA,
+                                step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA,
                                 out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)))
                 last = t == self.T - 1
                 self._timed("env_step", rep.env.step_into, rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
-                            rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t])
+                            rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t], t_base=self.step_dev)
                 if last:
                     rep.last_reward.copy_(rep.reward[t])
                     rep.last_done.copy_(rep.done[t])
-        self.t_global += self.T
+        self.step_dev.add_(self.T)
 
     def _bootstrap_and_gae(self) -> None:
         """ff_mappo.py:109-139."""
@@ -253,8 +285,7 @@ class FFLearner:
         EA = self.E * self.A
         for rep in self.reps:
             cx = rep.global_state[self.T].view(-1, self.Oc) if self.centralised else rep.agents_view[self.T].view(EA, self.Oa)
-            lv = ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share)
-            rep.last_val.view(-1).copy_(lv.view(-1))
+            ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share, out=rep.last_val.view(EA, 1))
             self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
                         rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
                         out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
@@ -319,7 +350,6 @@ class FFLearner:
         else:
             wait_perm = False
         self._rollout(n)
-        self._bootstrap_and_gae()
         if wait_perm:
             torch.cuda.current_stream(self.device).wait_event(self._perm_done)
         for k in range(self.K):

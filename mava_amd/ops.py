@@ -138,8 +138,11 @@ def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, row
 def policy_step(actor_params, critic_params, agents_view, action_mask, critic_input, *, n_actions: int,
                 critic_share: int = 1, critic_rows: Optional[int] = None, value_broadcast: int = 1, seed: int,
                 step: int, row_offset: int = 0, greedy: bool = False, forced_action=None, out=None,
-                want_logits: bool = False):
-    """One acting step: returns (action i32 (rows), log_prob (rows), value, logits|None)."""
+                want_logits: bool = False, step_base: Optional[torch.Tensor] = None):
+    """One acting step: returns (action i32 (rows), log_prob (rows), value, logits|None).  `step_base` (a device
+    int32 word) is added to `step` on the device."""
+    if step_base is not None:
+        _req(step_base, torch.int32, "step_base")
     _req(agents_view, torch.float32, "agents_view")
     rows, actor_din = agents_view.shape
     _req(critic_input, torch.float32, "critic_input")
@@ -176,7 +179,7 @@ def policy_step(actor_params, critic_params, agents_view, action_mask, critic_in
         lib().mava_policy_step_f32(ptr(actor_params), actor_din, n_actions, ptr(agents_view), ptr(action_mask),
                                    ptr(critic_params), critic_din, ptr(critic_input), critic_share, critic_rows,
                                    value_broadcast, rows, seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFF,
-                                   row_offset & 0xFFFFFFFF, int(greedy), ptr(forced_action), ptr(action),
+                                   ptr(step_base), row_offset & 0xFFFFFFFF, int(greedy), ptr(forced_action), ptr(action),
                                    ptr(log_prob), ptr(value), ptr(logits), stream_ptr()),
         "mava_policy_step_f32",
     )

@@ -90,7 +90,8 @@ def test_learner_update_matches_oracle(dev, system, U):
                         critic_lr=2e-3)
     ora.set_params(fa, fc)
 
-    for n in range(2):
+    for i in range(4):  # updates 3 and 4 replay the HIP graphs captured for n = 0, 1
+        n = i % 2
         perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
         L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
         torch.cuda.synchronize()
@@ -110,7 +111,35 @@ def test_learner_update_matches_oracle(dev, system, U):
         assert_close(L.p[L.Pa :].cpu().numpy() - fc, ora.pc - fc, 1e-3, "critic update")
         assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
         assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
-    assert L.count.cpu().tolist() == [2 * K * M, 2 * K * M]
+    assert L.count.cpu().tolist() == [4 * K * M, 4 * K * M]
+    assert len(L._graphs) == 2, "the rollout graphs were not captured"
+
+
+def test_graph_rollout_is_bit_identical(dev, monkeypatch):
+    """The captured rollout (device-side step counter) against the eager launches, 5 updates."""
+    from mava_amd import envs
+    from mava_amd.systems.ppo import ff_mappo
+
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAVA_GRAPH_ROLLOUT", flag)
+        cfg = _cfg("ff_mappo", 4, 16, 8, 2, 2, 2)
+        cfg.system.num_updates_per_eval = 1
+        cfg.env.kwargs.time_limit = 5
+        env, _ = envs.make(cfg, add_global_state=True, device=dev)
+        learn, _, state = ff_mappo.learner_setup(env, (3, 4, 5), cfg, device=dev)
+        L = learn.learner
+        assert L.graph_rollout == (flag == "1")
+        for _ in range(5):
+            out = learn(state)
+            state = out.learner_state
+        torch.cuda.synchronize()
+        assert len(L._graphs) == (1 if flag == "1" else 0)
+        finals.append((L.p.clone(), L.reps[1].action.clone(), L.reps[0].adv.clone(), L.reps[0].info_return.clone(),
+                       int(L.step_dev.item()), L.t_global))
+    for a, b in zip(finals[0][:4], finals[1][:4]):
+        assert torch.equal(a, b)
+    assert finals[0][4:] == finals[1][4:] == (40, 40)
 
 
 def test_learn_contract_shapes(dev):

@@ -135,7 +135,11 @@ class FFLearner:
         # the same counter on the device: the kernels add it to their relative step, so a rollout captured in a HIP
         # graph replays with the next counters
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=d)
-        self.graph_rollout = os.environ.get("MAVA_GRAPH_ROLLOUT", "1") != "0"
+        # Single-rank jobs only: with a process group the replay measured SLOWER (RCCL, one rank, forced exchange:
+        # 22.5 vs 22.1 ms per update; two gloo ranks on one card: 100x slower), see tools/graph_pg_rehearsal.py.
+        # MAVA_GRAPH_ROLLOUT=0 turns it off, =force keeps it on with several ranks.
+        mode = os.environ.get("MAVA_GRAPH_ROLLOUT", "1")
+        self.graph_rollout = mode == "force" or (mode != "0" and self.world == 1)
         self._graphs: Dict[Tuple[int, int], Any] = {}
         self._graph_seen: set = set()
         self.seed = int(s.seed)
@@ -237,8 +241,10 @@ class FFLearner:
             key = (n, self.seed)
             graph = self._graphs.get(key)
             if graph is None and key in self._graph_seen:
+                # thread_local: every launch of the rollout comes from this thread; RCCL's watchdog thread may query
+                # its events meanwhile
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._rollout_body(n)
                     self._bootstrap_and_gae()
                 self._graphs[key] = graph

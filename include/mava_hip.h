@@ -116,6 +116,31 @@ int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const f
                             int A, float clip_eps, float ent_coef, float* slab, long slab_stride,
                             int n_slab, mava_stream_t s);
 
+/* Continuous action head: Independent(TanhTransformed(Normal(loc, softplus(log_std) + 1e-3))),
+ * mava/networks.py:127-169 + mava/distributions.py:24-91 (log_prob clipped at +-0.999, sampled entropy).
+ * actor_params = [MLP(actor_din -> 128 -> 128 -> action_dim) | log_std(action_dim)], action_dim <= 16.
+ *
+ * mava_policy_step_continuous_f32: the acting step of mava_policy_step_f32 with action (rows, action_dim) float in
+ * (-1, 1) = tanh(loc + scale * noise) (greedy: the mode tanh(loc), distributions.py:75-77); forced_action (or NULL)
+ * scores given actions instead; mean (or NULL) receives loc.  The critic half is unchanged.
+ *
+ * mava_ppo_actor_grad_continuous_f32: _actor_loss_fn ff_mappo.py:150-180 for this head; the entropy sample of
+ * ff_mappo.py:176-177 is drawn from Philox(counter (row_offset + trajectory row, ent_step, dim/2), key seed).
+ * slab row = [MLP gradient | d/d log_std | actor_loss, entropy]; observation width <= 127. */
+int mava_policy_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+                                    const float* agents_view, const float* critic_params, int critic_din,
+                                    const float* critic_input, int critic_share, int critic_rows,
+                                    int value_broadcast, int rows, uint64_t seed, uint32_t step,
+                                    const uint32_t* step_base, uint32_t row_offset, int greedy,
+                                    const float* forced_action, float* action, float* log_prob, float* value,
+                                    float* mean, mava_stream_t s);
+int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim, const float* agents_view,
+                                       const float* action, const float* old_log_prob, const float* advantages,
+                                       const double* adv_stats, const int32_t* idx, long idx_base, int Rb, int A,
+                                       float clip_eps, float ent_coef, uint64_t seed, uint32_t ent_step,
+                                       uint32_t row_offset, float* slab, long slab_stride, int n_slab,
+                                       mava_stream_t s);
+
 /* _critic_loss_fn, ff_mappo.py:182-201.  critic_input row = agent_row / x_share.
  * slab tail: [value_loss, unused]. */
 int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_input, int x_share,

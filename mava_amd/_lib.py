@@ -44,6 +44,10 @@ _SIGNATURES = {
     "mava_mlp_forward_f32": [vp, i32, i32, vp, i32, i32, vp, vp],
     "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
                              vp, vp, vp, vp, vp, vp],
+    "mava_policy_step_continuous_f32": [vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
+                                        vp, vp, vp, vp, vp, vp],
+    "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32,
+                                           u32, vp, lng, i32, vp],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,

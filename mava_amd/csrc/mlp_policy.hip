@@ -12,6 +12,7 @@
 // the critic, so one launch covers 2 * ceil(R/32) wave-tiles (1024 at the BASELINE config-2
 // shape: one per SIMD).  W2/W3/biases are staged in LDS once per block.
 #include "mlp_coop_body.h"
+#include "tanh_normal.h"
 
 namespace {
 
@@ -71,6 +72,10 @@ struct StepOut {
   float* logits;        // optional (R, no) raw (unmasked) logits, for parity tests
   const int32_t* forced_action;  // optional: evaluate log_prob of given actions instead of sampling
   const uint32_t* step_base;     // optional device word added to `step` (captured HIP graphs replay with a moving counter)
+  // continuous head (tanh_normal.h) when action_f != nullptr: the network outputs are the means
+  float* action_f;               // (R, no) sampled actions in (-1, 1)
+  const float* log_std;          // (no) raw scale parameters
+  const float* forced_action_f;  // optional (R, no): score these actions instead of sampling
 };
 
 // Per-wave actor: block `bid` of the `nblk` actor blocks; each wave carries whole 32-row tiles through the three
@@ -90,6 +95,32 @@ __device__ __forceinline__ void actor_step_body(const FwdTask& actor, float* lds
     float y[NOA];
     forward_tile<NOA>(actor, lds, row, valid, h, j, y);
     const int no = actor.no;
+    if (out.action_f != nullptr) {  // uniform: continuous head, networks.py:127-169
+      const uint32_t gid = row_offset + (uint32_t)row;
+      float lp = 0.0f;
+#pragma unroll
+      for (int o = 0; o < NOA; ++o) {
+        if (o < no) {
+          const float sc = tn::scale_of(out.log_std[o]);
+          float a;
+          if (out.forced_action_f != nullptr) {
+            a = valid ? out.forced_action_f[(long)row * no + o] : 0.0f;
+          } else {
+            // sample = tanh(loc + scale * eps); mode = tanh(loc) (distributions.py:75-77)
+            const float eps = greedy ? 0.0f : tn::noise(gid, step, o, tn::STREAM_SAMPLE, seed_lo, seed_hi);
+            a = tanhf(fmaf(sc, eps, y[o]));
+          }
+          lp += tn::log_prob(a, y[o], sc).lp;
+          if (valid && h == 0) out.action_f[(long)row * no + o] = a;
+        }
+      }
+      if (valid && h == 0) {
+        out.log_prob[row] = lp;
+        if (out.logits != nullptr)
+          for (int o = 0; o < no && o < NOA; ++o) out.logits[(long)row * no + o] = y[o];
+      }
+      continue;
+    }
     Categorical<NOA> cat;
     cat.build(y, (mask != nullptr && valid) ? (mask + (long)row * no) : nullptr, no);
     int a = 0;
@@ -290,25 +321,26 @@ extern "C" int mava_mlp_forward_f32(const float* params, int din, int n_out, con
   return MAVA_OK;
 }
 
-extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
-                                    const float* agents_view, const uint8_t* action_mask,
-                                    const float* critic_params, int critic_din,
-                                    const float* critic_input, int critic_share, int critic_rows,
-                                    int value_broadcast, int rows, uint64_t seed, uint32_t step, const uint32_t* step_base,
-                                    uint32_t row_offset, int greedy, const int32_t* forced_action,
-                                    int32_t* action, float* log_prob, float* value, float* logits,
-                                    hipStream_t s) {
+// Both acting entry points; action_f != nullptr selects the continuous head (action / forced_action unused then).
+static int policy_step_impl(const float* actor_params, int actor_din, int n_actions,
+                            const float* agents_view, const uint8_t* action_mask,
+                            const float* critic_params, int critic_din,
+                            const float* critic_input, int critic_share, int critic_rows,
+                            int value_broadcast, int rows, uint64_t seed, uint32_t step, const uint32_t* step_base,
+                            uint32_t row_offset, int greedy, const int32_t* forced_action,
+                            int32_t* action, float* log_prob, float* value, float* logits,
+                            float* action_f, const float* forced_action_f, hipStream_t s) {
   MAVA_ARG_CHECK(actor_din >= 1 && critic_din >= 1 && n_actions >= 1 && n_actions <= 32, 0,
                  "mava_policy_step_f32: actor_din=%d critic_din=%d n_actions=%d unsupported",
                  actor_din, critic_din, n_actions);
   MAVA_ARG_CHECK(rows >= 0 && critic_rows >= 0 && critic_share >= 1 && value_broadcast >= 1, 1,
                  "mava_policy_step_f32: bad row counts");
   if (rows == 0 && critic_rows == 0) return MAVA_OK;
-  MAVA_ARG_CHECK(rows == 0 || (actor_params && agents_view && action && log_prob), 2,
+  MAVA_ARG_CHECK(rows == 0 || (actor_params && agents_view && (action || action_f) && log_prob), 2,
                  "mava_policy_step_f32: null actor pointer argument");
   MAVA_ARG_CHECK(critic_rows == 0 || (critic_params && critic_input && value), 2,
                  "mava_policy_step_f32: null critic pointer argument");
-  if (g_policy_variant == 2 && actor_din <= 288 && critic_din <= 288) {
+  if (g_policy_variant == 2 && actor_din <= 288 && critic_din <= 288 && action_f == nullptr) {
     int rc = MAVA_OK;
     if (rows > 0)
       rc = mava_coop_actor(actor_params, actor_din, n_actions, agents_view, action_mask, rows, seed, step, step_base, row_offset,
@@ -320,7 +352,8 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
   }
   FwdTask ta = {actor_params, agents_view, actor_din, n_actions, 1, pick_xv(agents_view, actor_din), rows};
   const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
-  StepOut so = {action, log_prob, value, logits, forced_action, step_base};
+  StepOut so = {action, log_prob, value, logits, forced_action, step_base, action_f,
+                actor_params ? actor_params + mlp_param_count(actor_din, n_actions) : nullptr, forced_action_f};
   // Few critic tiles (at most one per CU next to the actor's blocks): hybrid launch, cooperative critic blocks
   {
     const int tiles_c = mava_cdiv(critic_rows, 32);
@@ -360,4 +393,30 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
 #undef LAUNCH_STEP
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
+}
+
+extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
+                                    const float* agents_view, const uint8_t* action_mask,
+                                    const float* critic_params, int critic_din,
+                                    const float* critic_input, int critic_share, int critic_rows,
+                                    int value_broadcast, int rows, uint64_t seed, uint32_t step, const uint32_t* step_base,
+                                    uint32_t row_offset, int greedy, const int32_t* forced_action,
+                                    int32_t* action, float* log_prob, float* value, float* logits,
+                                    hipStream_t s) {
+  return policy_step_impl(actor_params, actor_din, n_actions, agents_view, action_mask, critic_params, critic_din,
+                          critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
+                          row_offset, greedy, forced_action, action, log_prob, value, logits, nullptr, nullptr, s);
+}
+
+extern "C" int mava_policy_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+                                               const float* agents_view, const float* critic_params, int critic_din,
+                                               const float* critic_input, int critic_share, int critic_rows,
+                                               int value_broadcast, int rows, uint64_t seed, uint32_t step,
+                                               const uint32_t* step_base, uint32_t row_offset, int greedy,
+                                               const float* forced_action, float* action, float* log_prob,
+                                               float* value, float* mean, hipStream_t s) {
+  MAVA_ARG_CHECK(rows == 0 || action != nullptr, 2, "mava_policy_step_continuous_f32: null action pointer");
+  return policy_step_impl(actor_params, actor_din, action_dim, agents_view, nullptr, critic_params, critic_din,
+                          critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
+                          row_offset, greedy, nullptr, nullptr, log_prob, value, mean, action, forced_action, s);
 }

@@ -28,6 +28,7 @@
 // writes ONE partial-gradient slab; mava_slab_reduce_f32 sums slabs in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).
 #include "mlp_core.h"
+#include "tanh_normal.h"
 
 namespace {
 
@@ -46,6 +47,8 @@ struct TrainTask {
   int Rb;                  // (t,e) rows in the minibatch; agent rows R = Rb * A
   const uint8_t* mask;     // (TE*A, no) or null
   const int32_t* action;   // (TE*A)
+  const float* action_f;   // continuous head: (TE*A, no) actions in (-1, 1); the raw scales follow the MLP in params
+  uint32_t seed_lo, seed_hi, ent_step, row_offset;  // continuous head: Philox key / counters of the entropy sample
   const float* old_logp;   // (TE*A)
   const float* adv;        // (TE*A)
   const double* stats;     // STATS_BLOCKS x {sum, sumsq} partials of the minibatch advantages
@@ -195,8 +198,9 @@ __device__ __forceinline__ float group_allreduce(float v, Op op) {
   return v;
 }
 
-template <int NO, int KT1, bool ACTOR, int XV>
+template <int NO, int KT1, bool ACTOR, int XV, bool CONT>
 __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLdsLayout L) {
+  static_assert(!CONT || ACTOR, "the continuous head belongs to the actor");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const W2s = lds + MlpLds<NO>::W2;
   float* const W3s = lds + MlpLds<NO>::W3;
@@ -282,6 +286,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
 #pragma unroll
   for (int r = 0; r < (ACTOR ? 1 : 16); ++r) aW3r[r] = 0.0f;
   float loss_a = 0.f, loss_b = 0.f;  // wave 0, half 0 lanes: actor (pg, entropy) / critic (value loss)
+  // continuous head: scale of this lane's action dimension, and the per-lane partial of d loss / d scale[lo]
+  float als = 0.0f;
+  const float ls_raw = CONT ? tk.params[mlp_param_count(tk.din, tk.no) + ((lane & (NO - 1)) < tk.no ? (lane & (NO - 1)) : 0)] : 0.0f;
+  const float sc_lo = CONT ? tn::scale_of(ls_raw) : 1.0f;
 
 
   // per-row inputs of the loss (row j of the tile), prefetched one tile ahead
@@ -299,7 +307,14 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   // per-row loss inputs (plain scalars, no aggregates: they must stay in registers)
   //   act: action ; f0, f1: actor old_logp, advantage / critic old_value, target ; m: raw mask byte of output lo
   auto load_row = [&](long fr, int& act, float& f0, float& f1, uint32_t& m) {
-    if (ACTOR) {
+    if (ACTOR && CONT) {
+      // component lo of the row's action vector (bit pattern, untouched here); m carries the row number, the
+      // counter of the entropy noise
+      act = __builtin_bit_cast(int, tk.action_f[fr * no + (lo < no ? lo : 0)]);
+      f0 = tk.old_logp[fr];
+      f1 = tk.adv[fr];
+      m = (uint32_t)fr;
+    } else if (ACTOR) {
       act = tk.action[fr];
       f0 = tk.old_logp[fr];
       f1 = tk.adv[fr];
@@ -572,6 +587,47 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     f32x16 dz;  // dz2 of tile w
     if (ACTOR) {
       const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
+      if (CONT) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int row = loss_row(q);
+          const bool rvalid = (it * 32 + row) < R;
+          const float* yp = YP + row * (NO + 1) + lo;
+          const float mean = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) +
+                             lds[MlpLds<NO>::B3 + lo];
+          // Independent(TanhTransformed(Normal(mean, scale))) over the NO lanes of the row (networks.py:127-169,
+          // distributions.py:24-91); entropy with a fresh reparameterised sample (ff_mappo.py:176-177)
+          const bool live = lo < no;
+          auto add_op = [](float a, float b) { return a + b; };
+          const tn::LogProb lpd = tn::log_prob(__builtin_bit_cast(float, r_act[q]), mean, sc_lo);
+          const float eps = tn::noise(tk.row_offset + r_m[q], tk.ent_step, lo, tn::STREAM_ENTROPY, tk.seed_lo, tk.seed_hi);
+          const float xsmp = fmaf(sc_lo, eps, mean);
+          const float th = tanhf(xsmp);
+          const float ent_d = 0.5f + tn::HALF_LOG_2PI + logf(sc_lo) + tn::tanh_fldj(xsmp);
+          const float lp = group_allreduce<NO>(live ? lpd.lp : 0.0f, add_op);
+          const float ent = group_allreduce<NO>(live ? ent_d : 0.0f, add_op);
+          const float gae = (r_f1[q] - adv_mean) * adv_rstd;
+          const float ratio = expf(lp - r_f0[q]);
+          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+          const float l1 = ratio * gae, l2 = rc * gae;
+          const float pg = -fminf(l1, l2);
+          const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
+          const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+          const float g2 = inside ? (1.0f - g1) : 0.0f;
+          const float dlp = rvalid ? (-(g1 + g2) * gae * ratio * invR) : 0.0f;
+          const float ec = rvalid ? (tk.ent_coef * invR) : 0.0f;
+          // d fldj / d x = -2 tanh(x); x = mean + scale * eps
+          const float dyo = live ? (dlp * lpd.dmean + ec * 2.0f * th) : 0.0f;
+          const float dsc = live ? (dlp * lpd.dscale - ec * (1.0f / sc_lo - 2.0f * th * eps)) : 0.0f;
+          DY[lo * LDT + row] = dyo;
+          ab3 += dyo;
+          als += dsc;
+          if (rvalid && lo == 0) {
+            loss_a += pg * invR;
+            loss_b += ent * invR;
+          }
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const int row = loss_row(q);
@@ -613,6 +669,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
           loss_a += pg * invR;
           loss_b += ent * invR;
         }
+      }
       }
       __syncthreads();  // B2: dy of all 32 rows visible
       // dz2^T[f][row] = sum_o W3[f][o] dy[o][row] on the MFMA (A: this lane's W3 words, kept in registers)
@@ -769,7 +826,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
   const int oB1 = mlp_off_b1(din), oW2 = mlp_off_w2(din), oB2 = mlp_off_b2(din), oW3 = mlp_off_w3(din),
             oB3 = mlp_off_b3(din, no);
-  const int P = mlp_param_count(din, no);
+  const int Pm = mlp_param_count(din, no);
+  const int P = CONT ? Pm + no : Pm;  // the loss sums follow the parameters (continuous head: MLP, then the raw scales)
 #pragma unroll
   for (int t = 0; t < KT1; ++t)
 #pragma unroll
@@ -806,8 +864,19 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
       loss_b += __shfl_down(loss_b, o, 64);
     }
     if (lane == 0) { red[4 * NO + 2 * w] = loss_a; red[4 * NO + 2 * w + 1] = loss_b; }
+    if (CONT) {
+      float u = als;
+#pragma unroll
+      for (int m = NO; m < 64; m <<= 1) u += __shfl_xor(u, m, 64);
+      if (lane < NO) red[4 * NO + 8 + w * NO + lane] = u;
+    }
     __syncthreads();
     if (tid < no) slab[oB3 + tid] = ((red[tid] + red[NO + tid]) + red[2 * NO + tid]) + red[3 * NO + tid];
+    if (CONT && tid < no) {
+      // d scale / d raw = softplus'(raw) = sigmoid(raw)
+      const float* ra = red + 4 * NO + 8;
+      slab[Pm + tid] = (((ra[tid] + ra[NO + tid]) + ra[2 * NO + tid]) + ra[3 * NO + tid]) * tn::sigmoid(tk.params[Pm + tid]);
+    }
     if (tid == 0) {
       slab[P] = ((red[4 * NO] + red[4 * NO + 2]) + red[4 * NO + 4]) + red[4 * NO + 6];
       slab[P + 1] = ((red[4 * NO + 1] + red[4 * NO + 3]) + red[4 * NO + 5]) + red[4 * NO + 7];
@@ -843,7 +912,7 @@ int pick_xv(const float* x, int din) {
   return (din % 4 == 0 && a % 16 == 0 && din >= 96) ? 4 : 1;
 }
 
-template <int NO, int KT1, bool ACTOR, int XV>
+template <int NO, int KT1, bool ACTOR, int XV, bool CONT>
 int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
   const TrainLdsLayout L = make_layout<NO>(KT1);
   const size_t lb = (size_t)L.end * sizeof(float);
@@ -852,37 +921,44 @@ int launch_train(const TrainTask& tk, int n_slab, hipStream_t s) {
                  lb, NO, tk.din);
   static bool attr_set = false;  // once per instantiation (lb is a function of the template arguments only)
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR, XV>,
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_kernel<NO, KT1, ACTOR, XV, CONT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR, XV>), dim3(n_slab), dim3(256), lb, s, tk, L);
+  hipLaunchKernelGGL((ppo_train_kernel<NO, KT1, ACTOR, XV, CONT>), dim3(n_slab), dim3(256), lb, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
 
-template <int NO, int KT1, bool ACTOR>
+template <int NO, int KT1, bool ACTOR, bool CONT>
 int launch_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
-  if (KT1 >= 4 && tk.xv == 4) return launch_train<NO, KT1, ACTOR, (KT1 >= 4 ? 4 : 1)>(tk, n_slab, s);
-  return launch_train<NO, KT1, ACTOR, 1>(tk, n_slab, s);
+  if (KT1 >= 4 && tk.xv == 4) return launch_train<NO, KT1, ACTOR, (KT1 >= 4 ? 4 : 1), CONT>(tk, n_slab, s);
+  return launch_train<NO, KT1, ACTOR, 1, CONT>(tk, n_slab, s);
 }
 
-template <int NO, bool ACTOR>
+template <int NO, bool ACTOR, bool CONT = false>
 int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int kt = tk.din / 32 + 1;  // 32*kt > din: the x tile always has a spare column for the ones (bias) input
 #ifdef MAVA_FAST_BUILD  // developer iteration: only the BASELINE config-2 instantiations
-  if (kt == 3) return launch_xv<NO, 3, ACTOR>(tk, n_slab, s);
-  if (kt == 9) return launch_xv<NO, 9, ACTOR>(tk, n_slab, s);
+  if (kt == 3) return launch_xv<NO, 3, ACTOR, CONT>(tk, n_slab, s);
+  if (kt == 9 && !CONT) return launch_xv<NO, 9, ACTOR, false>(tk, n_slab, s);
   mava_set_error("fast build: input width %d not instantiated", tk.din);
   return MAVA_EARG(9);
 #else
   switch (kt) {
-    case 1: return launch_xv<NO, 1, ACTOR>(tk, n_slab, s);
-    case 2: return launch_xv<NO, 2, ACTOR>(tk, n_slab, s);
-    case 3: return launch_xv<NO, 3, ACTOR>(tk, n_slab, s);
-    case 4: return launch_xv<NO, 4, ACTOR>(tk, n_slab, s);
-    case 5: case 6: return launch_xv<NO, 6, ACTOR>(tk, n_slab, s);
-    case 7: case 8: case 9: return launch_xv<NO, 9, ACTOR>(tk, n_slab, s);
+    case 1: return launch_xv<NO, 1, ACTOR, CONT>(tk, n_slab, s);
+    case 2: return launch_xv<NO, 2, ACTOR, CONT>(tk, n_slab, s);
+    case 3: return launch_xv<NO, 3, ACTOR, CONT>(tk, n_slab, s);
+    case 4: return launch_xv<NO, 4, ACTOR, CONT>(tk, n_slab, s);
+    default: break;
+  }
+  if (CONT) {  // the continuous head is instantiated for observation widths up to 127 (MaBrax-sized inputs)
+    mava_set_error("ppo_train (continuous head): input width %d > 127 is not instantiated", tk.din);
+    return MAVA_EARG(9);
+  }
+  switch (kt) {
+    case 5: case 6: return launch_xv<NO, 6, ACTOR, false>(tk, n_slab, s);
+    case 7: case 8: case 9: return launch_xv<NO, 9, ACTOR, false>(tk, n_slab, s);
     default:
       mava_set_error("ppo_train: input width %d > 287 is not instantiated", tk.din);
       return MAVA_EARG(9);
@@ -946,6 +1022,37 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
   if (n_actions <= 8) return dispatch_kt<8, true>(tk, n_slab, s);
   if (n_actions <= 16) return dispatch_kt<16, true>(tk, n_slab, s);
   return dispatch_kt<32, true>(tk, n_slab, s);
+}
+
+// Continuous action head (networks.py:127-169): params = [MLP(din -> 128 -> 128 -> action_dim) | log_std(action_dim)],
+// slab row = gradient in the same layout, then (actor_loss, entropy) sums.  The entropy term uses one reparameterised
+// sample per (row, dimension) from Philox(counter = (row_offset + trajectory row, ent_step, dim/2), key = seed).
+extern "C" int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim,
+                                                  const float* agents_view, const float* action,
+                                                  const float* old_log_prob, const float* advantages,
+                                                  const double* adv_stats, const int32_t* idx, long idx_base, int Rb,
+                                                  int A, float clip_eps, float ent_coef, uint64_t seed,
+                                                  uint32_t ent_step, uint32_t row_offset, float* slab,
+                                                  long slab_stride, int n_slab, hipStream_t s) {
+  MAVA_ARG_CHECK(din >= 1 && action_dim >= 1 && action_dim <= 16, 0,
+                 "mava_ppo_actor_grad_continuous_f32: din=%d action_dim=%d unsupported (action_dim <= 16)", din,
+                 action_dim);
+  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_slab >= 1 && n_slab <= 1024 && (long)Rb * A < (1L << 31), 1,
+                 "mava_ppo_actor_grad_continuous_f32: Rb=%d A=%d n_slab=%d", Rb, A, n_slab);
+  MAVA_ARG_CHECK(slab_stride >= mlp_param_count(din, action_dim) + action_dim + 2, 2,
+                 "mava_ppo_actor_grad_continuous_f32: slab_stride too small");
+  MAVA_ARG_CHECK(params && agents_view && action && old_log_prob && advantages && adv_stats && slab, 3,
+                 "mava_ppo_actor_grad_continuous_f32: null pointer argument");
+  TrainTask tk = {};
+  tk.params = params; tk.x = agents_view; tk.din = din; tk.no = action_dim; tk.xshare = 1; tk.agg = 1;
+  tk.xv = pick_xv(agents_view, din); tk.A = A; tk.idx = idx; tk.idx_base = idx_base; tk.Rb = Rb;
+  tk.action_f = action; tk.old_logp = old_log_prob; tk.adv = advantages;
+  tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
+  tk.slab_stride = slab_stride;
+  tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32); tk.ent_step = ent_step; tk.row_offset = row_offset;
+  tk.stamps = g_stamps;
+  if (action_dim <= 8) return dispatch_kt<8, true, true>(tk, n_slab, s);
+  return dispatch_kt<16, true, true>(tk, n_slab, s);
 }
 
 extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_input,

@@ -186,6 +186,96 @@ def policy_step(actor_params, critic_params, agents_view, action_mask, critic_in
     return action, log_prob, value, logits
 
 
+def continuous_param_count(din: int, action_dim: int) -> int:
+    """[MLP(din -> 128 -> 128 -> action_dim) | log_std(action_dim)] (networks.py:127-169, independent_std)."""
+    return mlp_param_count(din, action_dim) + action_dim
+
+
+def policy_step_continuous(actor_params, critic_params, agents_view, critic_input, *, action_dim: int,
+                           critic_share: int = 1, critic_rows: Optional[int] = None, value_broadcast: int = 1,
+                           seed: int, step: int, row_offset: int = 0, greedy: bool = False, forced_action=None,
+                           out=None, want_mean: bool = False, step_base: Optional[torch.Tensor] = None):
+    """One acting step with the continuous head: returns (action f32 (rows, action_dim), log_prob (rows), value,
+    mean|None)."""
+    if step_base is not None:
+        _req(step_base, torch.int32, "step_base")
+    _req(agents_view, torch.float32, "agents_view")
+    rows, actor_din = agents_view.shape
+    _req(critic_input, torch.float32, "critic_input")
+    critic_din = critic_input.shape[1]
+    if critic_rows is None:
+        critic_rows = critic_input.shape[0] * critic_share
+    if (critic_rows + critic_share - 1) // critic_share > critic_input.shape[0]:
+        raise ValueError("critic_input has too few rows")
+    _req(actor_params, torch.float32, "actor_params")
+    _req(critic_params, torch.float32, "critic_params")
+    if actor_params.numel() != continuous_param_count(actor_din, action_dim):
+        raise ValueError("actor_params: wrong size")
+    if critic_params.numel() != mlp_param_count(critic_din, 1):
+        raise ValueError("critic_params: wrong size")
+    if forced_action is not None:
+        _req(forced_action, torch.float32, "forced_action", (rows, action_dim))
+    dev = agents_view.device
+    if out is None:
+        action = torch.empty((rows, action_dim), dtype=torch.float32, device=dev)
+        log_prob = torch.empty(rows, dtype=torch.float32, device=dev)
+        value = torch.empty(critic_rows * value_broadcast, dtype=torch.float32, device=dev)
+    else:
+        action, log_prob, value = out
+        _req(action, torch.float32, "action")
+        _req(log_prob, torch.float32, "log_prob")
+        _req(value, torch.float32, "value")
+        if action.numel() != rows * action_dim or log_prob.numel() != rows or value.numel() != critic_rows * value_broadcast:
+            raise ValueError("out: wrong sizes")
+    mean = torch.empty((rows, action_dim), dtype=torch.float32, device=dev) if want_mean else None
+    check(
+        lib().mava_policy_step_continuous_f32(ptr(actor_params), actor_din, action_dim, ptr(agents_view),
+                                              ptr(critic_params), critic_din, ptr(critic_input), critic_share,
+                                              critic_rows, value_broadcast, rows, seed & 0xFFFFFFFFFFFFFFFF,
+                                              step & 0xFFFFFFFF, ptr(step_base), row_offset & 0xFFFFFFFF, int(greedy),
+                                              ptr(forced_action), ptr(action), ptr(log_prob), ptr(value), ptr(mean),
+                                              stream_ptr()),
+        "mava_policy_step_continuous_f32",
+    )
+    return action, log_prob, value, mean
+
+
+def ppo_actor_grad_continuous(params, agents_view, action, old_log_prob, advantages, stats, idx, idx_base: int,
+                              Rb: int, A: int, action_dim: int, clip_eps: float, ent_coef: float, seed: int,
+                              ent_step: int, row_offset: int, slab: torch.Tensor) -> None:
+    """Fills slab (n_slab, stride) with partial [MLP gradient | d log_std | actor_loss, entropy] sums."""
+    _req(agents_view, torch.float32, "agents_view")
+    rows, din = agents_view.shape
+    if rows % A:
+        raise ValueError("agents_view rows must be a multiple of A")
+    TE = rows // A
+    _req(params, torch.float32, "params")
+    P = continuous_param_count(din, action_dim)
+    if params.numel() != P:
+        raise ValueError(f"params: expected {P} floats")
+    _req(action, torch.float32, "action")
+    _req(old_log_prob, torch.float32, "old_log_prob")
+    _req(advantages, torch.float32, "advantages")
+    for n, t, k in (("action", action, action_dim), ("old_log_prob", old_log_prob, 1), ("advantages", advantages, 1)):
+        if t.numel() != rows * k:
+            raise ValueError(f"{n}: expected {rows * k} elements, got {t.numel()}")
+    _req(stats, torch.float64, "stats", (lib().mava_adv_stats_blocks(), 2))
+    _check_idx(idx, idx_base, Rb, TE)
+    if rows >= 2 ** 31:
+        raise ValueError("trajectory too large: TE*A must be < 2^31 (32-bit row arithmetic in the kernel)")
+    _req(slab, torch.float32, "slab")
+    if slab.dim() != 2 or slab.shape[1] < P + 2:
+        raise ValueError("slab must be (n_slab, >= P+2)")
+    check(
+        lib().mava_ppo_actor_grad_continuous_f32(ptr(params), din, action_dim, ptr(agents_view), ptr(action),
+                                                 ptr(old_log_prob), ptr(advantages), ptr(stats), ptr(idx), idx_base,
+                                                 Rb, A, clip_eps, ent_coef, seed & 0xFFFFFFFFFFFFFFFF,
+                                                 ent_step & 0xFFFFFFFF, row_offset & 0xFFFFFFFF, ptr(slab),
+                                                 slab.shape[1], slab.shape[0], stream_ptr()),
+        "mava_ppo_actor_grad_continuous_f32",
+    )
+
+
 def adv_stats(advantages: torch.Tensor, idx: Optional[torch.Tensor], idx_base: int, Rb: int, A: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """f64 (sum, sumsq) partials of the minibatch advantages, consumed by ppo_actor_grad."""

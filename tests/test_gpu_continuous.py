@@ -1,0 +1,121 @@
+"""GPU parity of the continuous action head (networks.py:127-169, distributions.py:24-91) against
+oracle/tanh_normal.py, through the C ABI.  The oracle restates tensorflow_probability's published formulas
+(checked against scipy in tests/test_oracle.py) - parity unpinned with respect to tfp itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+from oracle import tanh_normal as tn
+from tests.conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _params(rng, din, dim, head_scale=1.0):
+    mlp = po.mlp_flatten(po.init_mlp(rng, din, dim, head_scale))
+    return np.concatenate([mlp, rng.normal(size=dim) * 0.4]).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,din,dim,share", [(64, 20, 2, 1), (1000, 31, 6, 1), (96, 50, 9, 4), (33, 7, 1, 1),
+                                                (16384, 22, 2, 4)])
+def test_continuous_policy_step_matches_oracle(dev, rows, din, dim, share):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(rows + dim)
+    fa = _params(rng, din, dim)
+    cdin = 3 * din
+    fc = po.mlp_flatten(po.init_mlp(rng, cdin, 1, 1.0)).astype(np.float32)
+    av = rng.standard_normal((rows, din)).astype(np.float32)
+    cx = rng.standard_normal((rows // share, cdin)).astype(np.float32) if rows % share == 0 else None
+    if cx is None:
+        share, cx = 1, rng.standard_normal((rows, cdin)).astype(np.float32)
+    seed, step, off = 0x1234567890, 17, 1000
+    base = torch.tensor([5], dtype=torch.int32, device=dev)
+    act, lp, val, mean = ops.policy_step_continuous(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(cx, dev), action_dim=dim,
+                                                    critic_share=share, seed=seed, step=step - 5, step_base=base,
+                                                    row_offset=off, want_mean=True)
+    torch.cuda.synchronize()
+    fm, ls = tn.split_params(fa.astype(np.float64), din, dim)
+    mean64 = po.mlp_forward(po.mlp_unflatten(fm, din, dim), av.astype(np.float64))
+    assert_close(mean.cpu().numpy(), mean64, 1e-5, "mean")
+    eps = tn.normal_noise(seed, step, rows, dim, tn.STREAM_SAMPLE, row_offset=off)
+    a64, lp64 = tn.sample(mean64, ls, eps.astype(np.float64))
+    a = act.cpu().numpy()
+    assert np.all(np.abs(a) <= 1.0)
+    assert_close(a, a64, 1e-5, "actions", scale=1.0)
+    # log-prob of the actions the kernel actually took (atanh near the clip magnifies a 1-ulp action difference)
+    assert_close(lp.cpu().numpy(), tn.log_prob(a.astype(np.float64), mean64, ls), 2e-5, "log_prob", scale=1.0)
+    v64 = po.mlp_forward(po.mlp_unflatten(fc.astype(np.float64), cdin, 1), cx.astype(np.float64))[:, 0]
+    assert_close(val.cpu().numpy(), np.repeat(v64, share), 1e-5, "value")
+
+    # greedy = mode; forced actions (including both clipped tails) are scored, not sampled
+    g, _, _, _ = ops.policy_step_continuous(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(cx, dev), action_dim=dim,
+                                            critic_share=share, seed=seed, step=step, greedy=True)
+    assert_close(g.cpu().numpy(), np.tanh(mean64), 1e-5, "mode", scale=1.0)
+    forced = rng.uniform(-1, 1, size=(rows, dim)).astype(np.float32)
+    forced[0, 0], forced[1 % rows, dim - 1] = 0.99999, -1.0
+    f, flp, _, _ = ops.policy_step_continuous(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(cx, dev), action_dim=dim,
+                                              critic_share=share, seed=seed, step=step, forced_action=_t(forced, dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy(), forced)
+    assert_close(flp.cpu().numpy(), tn.log_prob(forced.astype(np.float64), mean64, ls), 2e-5, "forced log_prob", scale=1.0)
+
+
+@pytest.mark.parametrize("TE,A,O,dim,Rb,use_idx,n_slab", [(64, 4, 20, 2, 64, False, 3), (200, 2, 60, 6, 77, True, 8),
+                                                          (96, 3, 100, 9, 40, True, 2), (33, 1, 7, 1, 33, True, 1),
+                                                          (4096, 4, 22, 2, 2048, True, 256)])
+def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n_slab):
+    from mava_amd import ops
+
+    rng = np.random.default_rng(TE + dim)
+    rows, din = TE * A, O
+    flat = _params(rng, din, dim)
+    av = rng.standard_normal((rows, din)).astype(np.float32)
+    fm, ls = tn.split_params(flat.astype(np.float64), din, dim)
+    mean64 = po.mlp_forward(po.mlp_unflatten(fm, din, dim), av.astype(np.float64))
+    action = np.tanh(mean64 + tn.scale_of(ls) * rng.standard_normal((rows, dim))).astype(np.float32)
+    action[rng.random((rows, dim)) < 0.02] = 0.9995   # some actions in the clipped tails
+    action[rng.random((rows, dim)) < 0.02] = -1.0
+    # old log-probs close to the current ones: both sides of the clip range
+    old_lp = (tn.log_prob(action.astype(np.float64), mean64, ls) + rng.standard_normal(rows) * 0.25).astype(np.float32)
+    adv = rng.standard_normal(rows).astype(np.float32)
+    idx = rng.permutation(TE)[:Rb].astype(np.int32) if use_idx else np.arange(Rb, dtype=np.int32)
+    rows_sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
+    seed, ent_step, off = 99, 12345, 777
+
+    P = flat.size
+    slab = torch.zeros((n_slab, P + 2), device=dev)
+    stats = ops.adv_stats(_t(adv, dev), _t(idx, dev) if use_idx else None, 0, Rb, A)
+    ops.ppo_actor_grad_continuous(_t(flat, dev), _t(av, dev), _t(action, dev), _t(old_lp, dev), _t(adv, dev), stats,
+                                  _t(idx, dev) if use_idx else None, 0, Rb, A, dim, 0.2, 0.01, seed, ent_step, off, slab)
+    out = torch.zeros(P + 2, device=dev)
+    ops.slab_reduce(slab, P + 2, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+
+    eps = tn.normal_noise(seed, ent_step, 0, dim, tn.STREAM_ENTROPY, row_offset=off, gid=rows_sel).astype(np.float64)
+    tot, la, ent, g = tn.actor_loss_and_grad(flat.astype(np.float64), din, dim, av[rows_sel].astype(np.float64),
+                                             action[rows_sel].astype(np.float64), old_lp[rows_sel].astype(np.float64),
+                                             adv[rows_sel].astype(np.float64), 0.2, 0.01, eps)
+    # north_star: PPO gradients within 1e-4 rtol (tolerance form of BASELINE.md §2)
+    assert_close(got[: P - dim], g[: P - dim], 1e-4, "actor MLP grad")
+    assert_close(got[P - dim : P], g[P - dim :], 1e-4, "log_std grad")
+    assert_close(got[P:], np.array([la, ent]), 1e-5, "actor loss/entropy", scale=1.0)
+
+
+def test_continuous_actor_grad_rejects_wide_inputs(dev):
+    from mava_amd import ops
+    from mava_amd._lib import MavaHipError
+
+    din, dim, TE = 200, 2, 32
+    flat = torch.zeros(ops.continuous_param_count(din, dim), device=dev)
+    z = torch.zeros
+    with pytest.raises(MavaHipError, match="not instantiated"):
+        ops.ppo_actor_grad_continuous(flat, z((TE, din), device=dev), z((TE, dim), device=dev), z(TE, device=dev),
+                                      z(TE, device=dev), z((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=dev),
+                                      None, 0, TE, 1, dim, 0.2, 0.01, 1, 1, 0, z((1, flat.numel() + 2), device=dev))

@@ -238,3 +238,58 @@ def test_recurrent_param_layout():
     seg = ro.rec_unflatten(flat.numpy(), 155, 13)
     assert np.array_equal(cell["in"]["kernel"][0, 0].numpy(), seg["Wi"][:, 256:])
     assert np.array_equal(cell["hz"]["kernel"][0, 0].numpy(), seg["Wh"][:, 128:256])
+
+
+# ------------------------------------------------------------------ continuous action head
+def test_tanh_normal_formulas_against_scipy():
+    """oracle/tanh_normal.py against scipy's independent implementations of the same published formulas (the
+    reference delegates them to tensorflow_probability, which is not installable here: parity unpinned)."""
+    from scipy import special, stats
+
+    from oracle import tanh_normal as tn
+
+    z = np.array([-30.0, -12.0, -10.0, -9.99, -5.4, -1.0, 0.0, 2.0, 4.99, 5.01, 9.0])
+    np.testing.assert_allclose(tn.log_ndtr(z), special.log_ndtr(z), rtol=2e-4, atol=1e-12)
+    rng = np.random.default_rng(0)
+    mean, ls = rng.normal(size=(64, 3)), rng.normal(size=3) * 0.5
+    scale = tn.scale_of(ls)
+    np.testing.assert_allclose(scale, np.log1p(np.exp(ls)) + 1e-3, rtol=1e-12)
+    eps = rng.normal(size=(64, 3))
+    a, lp = tn.sample(mean, ls, eps)
+    a[0, 0], a[1, 1], a[2, 2] = 0.9995, -1.0, 0.999  # beyond / at the clipping threshold
+    lp = tn.log_prob(a, mean, ls)
+    x = np.arctanh(np.clip(a, -0.999, 0.999))
+    ref = stats.norm.logpdf(x, mean, scale) - np.log1p(-np.tanh(x) ** 2)
+    ath = np.arctanh(0.999)
+    ref = np.where(a >= 0.999, stats.norm.logsf(ath, mean, scale) - np.log(1 - 0.999), ref)
+    ref = np.where(a <= -0.999, stats.norm.logcdf(-ath, mean, scale) - np.log(1 - 0.999), ref)
+    np.testing.assert_allclose(lp, ref.sum(-1), rtol=1e-9, atol=1e-9)
+    # fldj of tanh
+    xs = np.linspace(-6, 6, 25)
+    np.testing.assert_allclose(tn.tanh_fldj(xs), np.log1p(-np.tanh(xs) ** 2), rtol=1e-7, atol=1e-10)
+    # Box-Muller noise: standard normal moments, distinct per dimension and row
+    n = tn.normal_noise(7, 3, 20000, 4, tn.STREAM_SAMPLE)
+    assert abs(n.mean()) < 0.02 and abs(n.std() - 1.0) < 0.02 and abs(np.corrcoef(n[:, 0], n[:, 1])[0, 1]) < 0.03
+
+
+def test_continuous_actor_gradient_finite_difference():
+    from oracle import tanh_normal as tn
+
+    rng = np.random.default_rng(1)
+    din, dim, R = 7, 3, 24
+    flat = np.concatenate([po.mlp_flatten(po.init_mlp(rng, din, dim, 1.0)), rng.normal(size=dim) * 0.3])
+    obs = rng.normal(size=(R, din))
+    mean = po.mlp_forward(po.mlp_unflatten(flat[:-dim], din, dim), obs)
+    a, old_lp = tn.sample(mean, flat[-dim:], rng.normal(size=(R, dim)))
+    a[0, 0], a[1, 1] = 0.9999, -0.9999  # both tail branches
+    old_lp = tn.log_prob(a, mean, flat[-dim:]) + rng.normal(size=R) * 0.1
+    adv, eps = rng.normal(size=R), rng.normal(size=(R, dim))
+    f = lambda p: tn.actor_loss_and_grad(p, din, dim, obs, a, old_lp, adv, 0.2, 0.01, eps)
+    total, la, ent, g = f(flat)
+    assert np.isfinite(total) and g.shape == flat.shape
+    idx = np.concatenate([rng.choice(flat.size - dim, 40, replace=False), np.arange(flat.size - dim, flat.size)])
+    for i in idx:
+        e = np.zeros_like(flat)
+        e[i] = 1e-6
+        fd = (f(flat + e)[0] - f(flat - e)[0]) / 2e-6
+        assert abs(fd - g[i]) <= 1e-5 * max(1.0, abs(g[i])), (i, fd, g[i])

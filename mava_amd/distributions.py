@@ -38,3 +38,44 @@ class Categorical:
         lsm = torch.log_softmax(self.logits, -1)
         p = lsm.exp()
         return -(torch.where(p > 0, p * lsm, torch.zeros_like(p))).sum(-1)
+
+
+class TanhNormal:
+    """Independent(TanhTransformedDistribution(Normal(loc, softplus(log_std) + 1e-3)), 1): mava/networks.py:127-169,
+    mava/distributions.py:24-91.  Host view for the evaluator seam like Categorical above; the rollout and the loss use
+    the fused kernels (mava_policy_step_continuous_f32, mava_ppo_actor_grad_continuous_f32)."""
+
+    THRESH = 0.999
+
+    def __init__(self, loc: torch.Tensor, log_std: torch.Tensor):
+        self.loc = loc
+        self.scale = torch.nn.functional.softplus(log_std) + 1e-3
+
+    def mode(self) -> torch.Tensor:
+        return torch.tanh(self.loc)  # distributions.py:75-77
+
+    def sample(self, seed: Optional[torch.Generator] = None) -> torch.Tensor:
+        eps = torch.randn(self.loc.shape, generator=seed, device=self.loc.device)
+        return torch.tanh(self.loc + self.scale * eps)
+
+    def log_prob(self, action: torch.Tensor) -> torch.Tensor:
+        import math
+
+        n = torch.distributions.Normal(self.loc, self.scale.expand_as(self.loc))
+        th = self.THRESH
+        ath, log_eps = math.atanh(th), math.log(1.0 - th)
+        yc = action.clamp(-th, th)
+        x = torch.atanh(yc)
+        inner = n.log_prob(x) - 2.0 * (math.log(2.0) - x - torch.nn.functional.softplus(-2.0 * x))
+        sn = torch.distributions.Normal(0.0, 1.0)
+        left = torch.log(sn.cdf((-ath - self.loc) / self.scale)) - log_eps
+        right = torch.log(sn.cdf((self.loc - ath) / self.scale)) - log_eps
+        return torch.where(yc <= -th, left, torch.where(yc >= th, right, inner)).sum(-1)
+
+    def entropy(self, seed: Optional[torch.Generator] = None) -> torch.Tensor:
+        import math
+
+        eps = torch.randn(self.loc.shape, generator=seed, device=self.loc.device)
+        x = self.loc + self.scale * eps
+        fldj = 2.0 * (math.log(2.0) - x - torch.nn.functional.softplus(-2.0 * x))
+        return (0.5 + 0.5 * math.log(2.0 * math.pi) + torch.log(self.scale) + fldj).sum(-1)

@@ -30,7 +30,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from . import ops, parallel
-from .networks import DiscreteActionHead, FeedForwardActor, FeedForwardValueNet, MLPTorso
+from .networks import FeedForwardActor, FeedForwardValueNet, MLPTorso, make_action_head
 from .types import (AdamState, ExperimentOutput, LearnerState, Observation, ObservationGlobalState, OptStates, Params,
                     TimeStep)
 
@@ -44,7 +44,7 @@ def _dist_info() -> Tuple[int, int]:
 class _Replica:
     """Trajectory + env buffers of one update-batch replica (the vmapped axis of ff_mappo.py:319)."""
 
-    def __init__(self, env, T: int, n_upd: int, critic_uses_state: bool, device):
+    def __init__(self, env, T: int, n_upd: int, critic_uses_state: bool, device, continuous: bool = False):
         E, A = env.num_envs, env.num_agents
         self.env = env
         self.state = env.alloc_state()
@@ -53,7 +53,9 @@ class _Replica:
         self.global_state = torch.empty((T + 1, E, env.gs_tiles, env.state_dim), device=d)
         self.action_mask = torch.empty((T + 1, E, A, env.action_dim), dtype=torch.uint8, device=d)
         self.step_count = torch.empty((T + 1, E, A), dtype=torch.int32, device=d)
-        self.action = torch.empty((T, E, A), dtype=torch.int32, device=d)
+        # discrete: action index per agent; continuous head: action vector in (-1, 1) per agent
+        self.action = (torch.empty((T, E, A, env.action_dim), device=d) if continuous
+                       else torch.empty((T, E, A), dtype=torch.int32, device=d))
         self.value = torch.empty((T, E, A), device=d)
         self.reward = torch.empty((T, E, A), device=d)
         self.log_prob = torch.empty((T, E, A), device=d)
@@ -91,9 +93,12 @@ class FFLearner:
             raise ValueError(f"env.num_envs={env.num_envs} != arch.num_envs={self.E}")
         if centralised_critic and not getattr(env, "add_global_state", False):
             raise ValueError("Global state must be provided to the centralised critic.")  # networks.py:196-197
+        # ff_mappo.py:348-350: the action head of the configuration, sized by the env's action dimension
+        action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
+        self.continuous = type(action_head).__name__ == "ContinuousActionHead"
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
-            self.reps.append(_Replica(rep_env, self.T, self.n_upd, centralised_critic, self.device))
+            self.reps.append(_Replica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
         env0 = self.reps[0].env
         self.A, self.nA = env0.num_agents, env0.action_dim
         config.system.num_agents = self.A  # ff_mappo.py:341
@@ -109,7 +114,7 @@ class FFLearner:
         net = config.network
         a_torso = MLPTorso(**{k: v for k, v in net.actor_network.pre_torso.items() if k != "_target_"})
         c_torso = MLPTorso(**{k: v for k, v in net.critic_network.pre_torso.items() if k != "_target_"})
-        self.actor_network = FeedForwardActor(a_torso, DiscreteActionHead(self.nA), self.Oa)
+        self.actor_network = FeedForwardActor(a_torso, action_head, self.Oa)
         self.critic_network = FeedForwardValueNet(c_torso, centralised_critic, self.Oc)
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
         self.P = self.Pa + self.Pc
@@ -132,6 +137,7 @@ class FFLearner:
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
         self.perm_gen = torch.Generator(device=d)
         self.t_global = 0  # env steps taken per env so far (Philox step counter)
+        self.ent_step = 0  # minibatches trained so far: counter of the continuous head's entropy sample
         # the same counter on the device: the kernels add it to their relative step, so a rollout captured in a HIP
         # graph replays with the next counters
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=d)
@@ -168,6 +174,7 @@ class FFLearner:
         for rep in self.reps:
             rep.env.step_into(rep.state, 0, rep.obs_slot(0), is_reset=True)
         self.t_global = 0
+        self.ent_step = 0
         self.step_dev.zero_()
         self.perm_gen.manual_seed(self.seed)
 
@@ -271,11 +278,17 @@ class FFLearner:
                 # a critic input row shared by the A agents of an env (critic_share == A) is evaluated once and its
                 # value written to all A agent slots - the same numbers as A identical forward passes
                 shared = self.critic_share == self.A and self.A > 1
-                self._timed("policy_step", ops.policy_step, pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx, n_actions=self.nA,
-                                critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
-                                value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
-                                step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA,
-                                out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)))
+                common = dict(critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
+                              value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
+                              step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA)
+                if self.continuous:
+                    self._timed("policy_step", ops.policy_step_continuous, pa, pc, av, cx, action_dim=self.nA,
+                                out=(rep.action[t].view(EA, self.nA), rep.log_prob[t].view(EA), rep.value[t].view(EA)),
+                                **common)
+                else:
+                    self._timed("policy_step", ops.policy_step, pa, pc, av, rep.action_mask[t].view(EA, self.nA), cx,
+                                n_actions=self.nA,
+                                out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)), **common)
                 last = t == self.T - 1
                 self._timed("env_step", rep.env.step_into, rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
                             rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t], t_base=self.step_dev)
@@ -308,9 +321,15 @@ class FFLearner:
         for u, rep in enumerate(self.reps):
             av = rep.agents_view[:T].view(TEA, self.Oa)
             ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
-            self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA), rep.action.view(TEA),
-                        rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA,
-                        float(s.clip_eps), float(s.ent_coef), self.slab_a)
+            if self.continuous:
+                self._timed("actor_grad", ops.ppo_actor_grad_continuous, pa, av, rep.action.view(TEA, self.nA),
+                            rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA,
+                            float(s.clip_eps), float(s.ent_coef), self.seed, self.ent_step,
+                            (self.rank * self.U + u) * TEA, self.slab_a)
+            else:
+                self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
+                            rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base,
+                            self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a)
             ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
         # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
         # the critic's backward kernels run on this one
@@ -330,6 +349,7 @@ class FFLearner:
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
                       num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
                       ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
+        self.ent_step += 1
 
     def _permutations_async(self) -> List[torch.Tensor]:
         """ff_mappo.py:272-273: one permutation of the T*E rows per epoch, identical on every replica and rank (the

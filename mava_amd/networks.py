@@ -1,5 +1,5 @@
 """Network definitions behind the reference's module names (mava/networks.py:39-58 MLPTorso,
-:88-124 DiscreteActionHead, :172-183 FeedForwardActor, :186-207 FeedForwardValueNet).
+:88-124 DiscreteActionHead, :127-169 ContinuousActionHead, :172-183 FeedForwardActor, :186-207 FeedForwardValueNet).
 
 A network here is (a) a flat float32 parameter vector in the kernel layout
 [W1(din,128) | b1 | W2(128,128) | b2 | W3(128,n_out) | b3] and (b) a Flax-shaped tree of VIEWS into
@@ -14,7 +14,7 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from .distributions import Categorical
+from .distributions import Categorical, TanhNormal
 from .types import Observation, ObservationGlobalState
 
 HIDDEN = 128
@@ -44,6 +44,30 @@ class DiscreteActionHead:
 
     def __init__(self, action_dim: int, **_: Any):
         self.action_dim = int(action_dim)
+
+
+class ContinuousActionHead:
+    """mava/networks.py:127-169: loc = Dense(action_dim), scale = softplus(log_std) + min_scale with an
+    observation-independent log_std parameter; actions in [-1, 1] through a tanh bijector."""
+
+    def __init__(self, action_dim: int, min_scale: float = 1e-3, independent_std: bool = True, **_: Any):
+        self.action_dim = int(action_dim)
+        if not independent_std or abs(float(min_scale) - 1e-3) > 1e-12:
+            raise NotImplementedError("mava_amd's kernels implement ContinuousActionHead(min_scale=1e-3, independent_std=True) "
+                                      f"(the reference's defaults); got min_scale={min_scale}, independent_std={independent_std}")
+        if self.action_dim > 16:
+            raise NotImplementedError(f"continuous action heads are instantiated up to 16 dimensions, got {self.action_dim}")
+
+
+def make_action_head(cfg: Any, action_dim: int):
+    """hydra.utils.instantiate(config.network.action_head, action_dim=env.action_dim), ff_mappo.py:348-350."""
+    kw = {k: v for k, v in dict(cfg).items() if k != "_target_"} if cfg is not None else {}
+    target = str(dict(cfg).get("_target_", "mava.networks.DiscreteActionHead")) if cfg is not None else ""
+    if target.endswith("ContinuousActionHead"):
+        return ContinuousActionHead(action_dim, **kw)
+    if target == "" or target.endswith("DiscreteActionHead"):
+        return DiscreteActionHead(action_dim, **kw)
+    raise NotImplementedError(f"unknown action head {target}")
 
 
 def _orthogonal_(w: torch.Tensor, scale: float, gen: torch.Generator) -> None:
@@ -128,28 +152,63 @@ class _FeedForwardNet:
 
 
 class FeedForwardActor(_FeedForwardNet):
-    """mava/networks.py:172-183 with DiscreteActionHead (:88-124): head Dense init orthogonal(0.01)."""
+    """mava/networks.py:172-183 with DiscreteActionHead (:88-124) or ContinuousActionHead (:127-169): head Dense
+    init orthogonal(0.01); the continuous head appends its log_std vector (zeros) to the flat parameters."""
 
     head_scale = 0.01
 
-    def __init__(self, torso: MLPTorso, action_head: DiscreteActionHead, obs_dim: int):
+    def __init__(self, torso: MLPTorso, action_head, obs_dim: int):
         super().__init__(obs_dim, action_head.action_dim)
         torso.require([HIDDEN, HIDDEN])
         self.torso, self.action_head = torso, action_head
+        self.continuous = isinstance(action_head, ContinuousActionHead)
+        self.num_mlp_params = self.num_params
+        if self.continuous:
+            self.num_params += self.n_out
+
+    def init_flat(self, seed: int, device=None) -> torch.Tensor:
+        flat = torch.zeros(self.num_params, dtype=torch.float32)  # log_std: nn.initializers.zeros (networks.py:141)
+        flat[: self.num_mlp_params].copy_(super().init_flat(seed)[: self.num_mlp_params])
+        return flat.to(device) if device is not None else flat
+
+    def _log_std(self, flat: torch.Tensor) -> torch.Tensor:
+        return flat[self.num_mlp_params : self.num_mlp_params + self.n_out]
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        out = super().tree(flat, lead)
+        if self.continuous:
+            ls = self._log_std(flat)
+            out["params"]["action_head"]["log_std"] = ls.expand(*lead, self.n_out) if lead else ls
+        return out
+
+    def flat_from_tree(self, tree: Dict[str, Any], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            leaf = tree["params"]["torso"]["Dense_0"]["bias"]
+            out = torch.empty(self.num_params, dtype=torch.float32, device=leaf.device)
+        super().flat_from_tree(tree, out)
+        if self.continuous:
+            ls = tree["params"]["action_head"]["log_std"]
+            while ls.dim() > 1:
+                ls = ls[0]
+            self._log_std(out).copy_(ls)
+        return out
 
     def _assemble(self, torso, head):
-        return {"torso": torso, "action_head": {"Dense_0": head}}
+        return {"torso": torso, "action_head": {("mean" if self.continuous else "Dense_0"): head}}
 
     def _disassemble(self, p):
-        return p["torso"], p["action_head"]["Dense_0"]
+        return p["torso"], p["action_head"]["mean" if self.continuous else "Dense_0"]
 
-    def apply(self, params: Any, observation) -> Categorical:
+    def apply(self, params: Any, observation):
         """actor_network.apply(params, observation) -> distribution (mava/evaluator.py:182-183)."""
         flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
         av = observation.agents_view
         lead = av.shape[:-1]
         x = av.reshape(-1, av.shape[-1]).contiguous().float()
-        logits = ops.mlp_forward(flat.contiguous(), self.din, self.n_out, x)
+        flat = flat.contiguous()
+        logits = ops.mlp_forward(flat[: self.num_mlp_params], self.din, self.n_out, x)
+        if self.continuous:
+            return TanhNormal(logits.view(*lead, self.n_out), self._log_std(flat))
         mask = observation.action_mask
         return Categorical(logits.view(*lead, self.n_out), None if mask is None else mask.reshape(*lead, self.n_out))
 

@@ -16,13 +16,16 @@ import numpy as np
 
 from . import philox
 from . import ppo_oracle as po
+from . import tanh_normal as tn
 from .synth_env import SynthRware
 
 
 class OracleLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, D=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95,
                  clip_eps=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4,
-                 decay=False, num_updates=1, time_limit=500, shared_gs=True):
+                 decay=False, num_updates=1, time_limit=500, shared_gs=True, continuous=False):
+        self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
+        self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U, self.D = E, A, O, nA, T, K, M, U, D
         self.centralised, self.seed = centralised, seed
         self.h = dict(gamma=gamma, lam=gae_lambda, clip=clip_eps, ent=ent_coef, vf=vf_coef, mgn=max_grad_norm,
@@ -49,7 +52,7 @@ class OracleLearner:
         """ff_mappo.py:76-106 for one (rank, replica)."""
         E, A, T, nA = self.E, self.A, self.T, self.nA
         env, obs = self.envs[d][u], self.obs[d][u]
-        pa, pc = po.mlp_unflatten(self.pa, self.Oa, nA), po.mlp_unflatten(self.pc, self.Oc, 1)
+        pa, pc = po.mlp_unflatten(self.pa[: po.mlp_param_count(self.Oa, nA)], self.Oa, nA), po.mlp_unflatten(self.pc, self.Oc, 1)
         tr = {k: [] for k in ("av", "cx", "mask", "action", "value", "reward", "log_prob", "done", "ret", "len", "term")}
         for t in range(T):
             step = self.t_global + t
@@ -57,13 +60,20 @@ class OracleLearner:
             cx = self._critic_in(obs)
             mask = obs["action_mask"]
             y = po.mlp_forward(pa, av.reshape(E * A, -1))
-            z = po.masked_logits(y, mask.reshape(E * A, nA))
-            uni = philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=(d * self.U + u) * E * A)
-            action = po.gumbel_argmax(z, uni)
-            lp = po.log_softmax(z)[np.arange(E * A), action]
+            if self.continuous:
+                eps = tn.normal_noise(self.seed, step, E * A, nA, tn.STREAM_SAMPLE, row_offset=(d * self.U + u) * E * A)
+                # the action is stored in float32 (the trajectory dtype) and scored as stored
+                action = tn.sample(y, self.pa[-nA:], eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
+                lp = tn.log_prob(action, y, self.pa[-nA:])
+                action = action.reshape(E, A, nA)
+            else:
+                z = po.masked_logits(y, mask.reshape(E * A, nA))
+                uni = philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=(d * self.U + u) * E * A)
+                action = po.gumbel_argmax(z, uni).reshape(E, A)
+                lp = po.log_softmax(z)[np.arange(E * A), action.reshape(-1)]
             value = po.mlp_forward(pc, cx.reshape(E * A, -1))[:, 0]
             obs, reward, done, info = env.step(step + 1)
-            for k, v in (("av", av), ("cx", cx), ("mask", mask), ("action", action.reshape(E, A)), ("value", value.reshape(E, A)),
+            for k, v in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", value.reshape(E, A)),
                          ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done", done),
                          ("ret", info["episode_return"]), ("len", info["episode_length"]), ("term", info["is_terminal_step"])):
                 tr[k].append(v)
@@ -96,10 +106,18 @@ class OracleLearner:
                         tr = trajs[d][u]
                         sel = lambda x: flat(x)[rows]
                         R = rows.size * A
-                        _, la, ent, g1 = po.actor_loss_and_grad(
-                            self.pa, self.Oa, nA, sel(tr["av"]).reshape(R, -1), sel(tr["mask"]).reshape(R, nA),
-                            sel(tr["action"]).reshape(R), sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R),
-                            h["clip"], h["ent"])
+                        if self.continuous:
+                            gid = (rows[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)  # trajectory rows
+                            eps = tn.normal_noise(self.seed, self.ent_step, 0, nA, tn.STREAM_ENTROPY,
+                                                  row_offset=(d * self.U + u) * T * E * A, gid=gid).astype(np.float64)
+                            _, la, ent, g1 = tn.actor_loss_and_grad(
+                                self.pa, self.Oa, nA, sel(tr["av"]).reshape(R, -1), sel(tr["action"]).reshape(R, nA),
+                                sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R), h["clip"], h["ent"], eps)
+                        else:
+                            _, la, ent, g1 = po.actor_loss_and_grad(
+                                self.pa, self.Oa, nA, sel(tr["av"]).reshape(R, -1), sel(tr["mask"]).reshape(R, nA),
+                                sel(tr["action"]).reshape(R), sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R),
+                                h["clip"], h["ent"])
                         _, vl, g2 = po.critic_loss_and_grad(
                             self.pc, self.Oc, sel(tr["cx"]).reshape(R, -1), sel(tr["value"]).reshape(R),
                             sel(tr["tgt"]).reshape(R), h["clip"], h["vf"])
@@ -114,4 +132,5 @@ class OracleLearner:
                 self.pc, self.mc, self.vc, self.counts[1] = po.clip_adam(self.pc, gc, self.mc, self.vc, self.counts[1], lrc, h["mgn"])
                 la, ent, vl = info
                 metrics[k, mb] = [(la - h["ent"] * ent) + h["vf"] * vl, vl, la, ent]  # ff_mappo.py:255-265
+                self.ent_step += 1
         return {"train_metrics": metrics}

@@ -119,3 +119,71 @@ def test_continuous_actor_grad_rejects_wide_inputs(dev):
         ops.ppo_actor_grad_continuous(flat, z((TE, din), device=dev), z((TE, dim), device=dev), z(TE, device=dev),
                                       z(TE, device=dev), z((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=dev),
                                       None, 0, TE, 1, dim, 0.2, 0.01, 1, 1, 0, z((1, flat.numel() + 2), device=dev))
+
+
+@pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])
+def test_continuous_learner_update_matches_oracle(dev, system, U):
+    """The whole PPO update with network.action_head = ContinuousActionHead (the reference selects it with exactly this
+    override for MaBrax) on a MaBrax-shaped synthetic env, against the NumPy whole-update oracle."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import ff_ippo, ff_mappo
+    from oracle.ppo_loop import OracleLearner
+
+    E, A, O, dim, T, K, M = 8, 2, 12, 3, 16, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}",
+                                        "network.action_head._target_=mava.networks.ContinuousActionHead"])
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": dim}
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr = 1e-3
+    cfg.system.critic_lr = 2e-3
+    central = system == "ff_mappo"
+    mod = ff_mappo if central else ff_ippo
+    env, eval_env = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    assert L.continuous and L.reps[0].action.shape == (T, E, A, dim)
+    head = state.params.actor_params["params"]["action_head"]
+    assert head["mean"]["kernel"].shape == (1, U, 128, dim) and head["log_std"].shape == (1, U, dim)
+
+    rng = np.random.default_rng(0)
+    fa = np.concatenate([po.mlp_flatten(po.init_mlp(rng, A + O, dim, 1.0)), rng.normal(size=dim) * 0.3]).astype(np.float32)
+    fc = po.mlp_flatten(po.init_mlp(rng, (A * O) if central else (A + O), 1, 1.0)).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleLearner(E=E, A=A, O=O, nA=dim, T=T, K=K, M=M, U=U, D=1, centralised=central, seed=42, actor_lr=1e-3,
+                        critic_lr=2e-3, continuous=True)
+    ora.set_params(fa, fc)
+    for i in range(3):  # the third update replays the rollout graph captured for n = 0
+        n = i % 2
+        perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[0][u]
+            assert_close(rep.action.cpu().numpy(), tr["action"], 1e-5, "actions", scale=1.0)
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-4, "log_probs", scale=1.0)
+            assert_close(rep.value.cpu().numpy(), tr["value"], 1e-5, "values")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], 1e-5, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
+        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+    # evaluator seam: the host distribution view agrees with the kernels' acting step
+    from mava_amd.evaluator import get_eval_fn, make_ff_eval_act_fn
+
+    out = learn(L.learner_state())
+    pi = actor_network.apply(out.learner_state.params.actor_params, out.learner_state.timestep.observation)
+    a = pi.mode()
+    assert a.shape == (1, U, E, A, dim) and float(a.abs().max()) <= 1.0
+    fm, ls = tn.split_params(L.p[: L.Pa].double().cpu().numpy(), A + O, dim)
+    mean = pi.loc.double().cpu().numpy()
+    acts = np.tanh(mean + 0.3)
+    assert_close(pi.log_prob(torch.from_numpy(acts).float().to(dev)).cpu().numpy(), tn.log_prob(acts, mean, ls), 1e-4,
+                 "host log_prob", scale=1.0)
+    ev = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
+    m = ev(out.learner_state.params.actor_params, 0)
+    assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes

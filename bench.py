@@ -75,7 +75,16 @@ def main() -> None:
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-critic-aggregation", action="store_true",
                     help="centralised critic: one network pass per AGENT row (the reference's A identical passes) instead of one per (t,e) row")
+    ap.add_argument("--action-head", default="discrete", choices=["discrete", "continuous"],
+                    help="continuous: network.action_head=ContinuousActionHead on a MaBrax-shaped synthetic env "
+                         "(--agents, --obs-dim, --action-dim; SURVEY 8f N4) - a secondary workload, not the headline metric")
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--obs-dim", type=int, default=27)
+    ap.add_argument("--action-dim", type=int, default=2)
     args = ap.parse_args()
+    continuous = args.action_head == "continuous"
+    if continuous and not args.system.startswith("ff"):
+        raise SystemExit("the continuous head is built for ff_ippo / ff_mappo")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +115,10 @@ def main() -> None:
     E = args.envs // U
     cfg = compose(f"default_{args.system}", [f"env={args.env}", f"env/scenario={args.scenario}", f"arch.num_envs={E}",
                                               f"system.update_batch_size={U}"])
+    if continuous:
+        cfg.network.action_head = {"_target_": "mava.networks.ContinuousActionHead"}
+        cfg.env.scenario.task_config.num_agents = args.agents
+        cfg.env.synthetic = {"obs_dim": args.obs_dim, "num_actions": args.action_dim}
     cfg.system.num_updates_per_eval = 1
     cfg.system.num_updates = max(args.steps + args.warmup, 1)
     central = args.system.endswith("mappo")
@@ -162,7 +175,9 @@ def main() -> None:
     log(f"timed region: {args.steps} updates in {elapsed:.3f} s -> {value:,.0f} env-steps/s")
 
     out = {
-        "metric": ("env-steps/sec (whole node), ff_mappo RWARE tiny-4ag" if args.system == "ff_mappo" and args.env == "rware"
+        "metric": ("env-steps/sec (whole node), ff_mappo RWARE tiny-4ag"
+                   if args.system == "ff_mappo" and args.env == "rware" and not continuous
+                   else f"env-steps/sec (whole node), {args.system} continuous-action synthetic (MaBrax-shaped)" if continuous
                    else f"env-steps/sec (whole node), {args.system} {args.env} {args.scenario}"),
         "value": value,
         "unit": "env-steps/s",
@@ -175,7 +190,8 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.system} {args.env.upper()} {args.scenario}-shaped synthetic obs, {E * U} envs/GPU "
+        "config": {"workload": (f"{args.system} ContinuousActionHead, MaBrax-shaped synthetic obs, " if continuous else
+                                f"{args.system} {args.env.upper()} {args.scenario}-shaped synthetic obs, ") + f"{E * U} envs/GPU "
                                f"(update_batch_size={U} x num_envs={E}), rollout_length={T}, ppo_epochs={K}, "
                                f"num_minibatches={M}, agents={A}, obs={L.Oa}/{L.Oc}, actions={L.nA}, "
                                f"one step = one PPO update = {T * U * E} env-steps per GPU",
@@ -191,7 +207,7 @@ def main() -> None:
     except (OSError, ValueError, KeyError):
         pass
     default_shape = (args.envs == 4096 and args.update_batch_size == 1 and args.scenario == "tiny-4ag"
-                     and args.system == "ff_mappo")
+                     and args.system == "ff_mappo" and not continuous)
 
     if rank == 0 and getattr(L, "timers", None):
         timers = {k: _ev_ms(v) for k, v in L.timers.items()}
@@ -237,7 +253,7 @@ def main() -> None:
         per_update = {k: sum(v) / timer_steps for k, v in timers.items()}
         out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in per_update.items()}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("ff"):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("ff") and not continuous:
         from oracle import cpu_loop
 
         cores = usable_cores()

@@ -83,8 +83,6 @@ def main() -> None:
     ap.add_argument("--action-dim", type=int, default=2)
     args = ap.parse_args()
     continuous = args.action_head == "continuous"
-    if continuous and not args.system.startswith("ff"):
-        raise SystemExit("the continuous head is built for ff_ippo / ff_mappo")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

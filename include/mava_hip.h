@@ -211,6 +211,20 @@ int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const in
                             const float* old_log_prob, const float* advantages, const double* adv_stats,
                             int n_stats, float clip_eps, float ent_coef, float* dlogits,
                             float* loss_partials, int n_blocks, mava_stream_t s);
+/* Continuous head on the recurrent systems (rec_mappo.py:210-242 with networks.py:127-169): `mean` / `dmean` are T32
+ * (T*Rm x action_dim) like logits / dlogits of mava_seq_actor_loss_f32, `action` is the external (T, E, A, action_dim)
+ * buffer, `log_std` the action_dim raw scales; dscale_partials (n_blocks x action_dim) receives d loss / d log_std
+ * partials (already times sigmoid(log_std)).  Entropy noise: Philox counter (row_offset + trajectory row, ent_step, dim/2). */
+int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
+                                       const float* mean, const float* log_std, const float* action,
+                                       const float* old_log_prob, const float* advantages, const double* adv_stats,
+                                       int n_stats, float clip_eps, float ent_coef, uint64_t seed, uint32_t ent_step,
+                                       uint32_t row_offset, float* dmean, float* loss_partials, float* dscale_partials,
+                                       int n_blocks, mava_stream_t s);
+/* rollout epilogue: T32 means of one step -> action (rows, action_dim) = tanh(loc + scale * noise), log_prob (rows) */
+int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std, uint64_t seed,
+                                   uint32_t step, uint32_t row_offset, int greedy, float* action, float* log_prob,
+                                   mava_stream_t s);
 /* agents_per_row = 1: one value per agent row (T, E, A).  agents_per_row = n > 1 (then A must be 1): the rows are
  * (t, env) rows whose n agents share the critic input (centralised critic on a tiled global state); old_value /
  * targets are (T, E, n) and the row's gradient is the sum of its agents' loss gradients - the same gradient as n

@@ -13,6 +13,7 @@
 // wave fed by 64 LDS reads of the (transposed) previous hidden state - no weight traffic at all.
 // Activations use the T32 tile layout (rec_dense.hip): accumulator-shaped loads/stores are coalesced.
 #include "mlp_core.h"
+#include "tanh_normal.h"
 
 namespace {
 
@@ -280,6 +281,12 @@ struct SeqLossTask {
   int32_t* action_out;       // external (E, A) slot
   float* logp_out;
   float* value_out;
+  // continuous head (tanh_normal.h): y holds the means
+  const float* log_std;      // (no) raw scales
+  const float* action_f;     // external (T, E, A, no) actions in (-1, 1)
+  float* action_f_out;       // external (E, A, no) slot
+  float* dscale_partials;    // (gridDim.x, no): d loss / d log_std partials
+  uint32_t ent_step;
 };
 
 template <int NO, bool ACTOR>
@@ -417,6 +424,121 @@ __global__ __launch_bounds__(256) void seq_sample_kernel(SeqLossTask tk) {
   tk.logp_out[q] = lp;
 }
 
+// Continuous head of the sequence loss (rec_mappo.py:210-242 with networks.py:127-169 / distributions.py:24-91): the
+// same row walk as seq_loss_kernel<NO, true>; a thread owns all `no` action dimensions of its row.
+template <int NO>
+__global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
+  __shared__ float red[2 + NO][4];
+  __shared__ float st[2];
+  const long R = (long)tk.T * tk.Rm;
+  const float invR = 1.0f / (float)R;
+  if (threadIdx.x == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < tk.n_stats; ++i) { s1 += tk.stats[2 * i]; s2 += tk.stats[2 * i + 1]; }
+    const double mean = s1 / (double)R;
+    double var = s2 / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[0] = (float)mean;
+    st[1] = 1.0f / ((float)sqrt(var) + 1e-8f);
+  }
+  __syncthreads();
+  float sc[NO], ds[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    sc[o] = tn::scale_of(tk.log_std[o < tk.no ? o : 0]);
+    ds[o] = 0.0f;
+  }
+  float la = 0.0f, lb = 0.0f;
+  const float lo = 1.0f - tk.clip_eps, hi = 1.0f + tk.clip_eps;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < R; q += (long)gridDim.x * 256) {
+    const int t = (int)(q / tk.Rm), m = (int)(q - (long)t * tk.Rm);
+    const int e_local = m / tk.A, a = m - e_local * tk.A;
+    const int env = tk.idx ? tk.idx[e_local] : e_local;
+    const long er = ((long)t * tk.E + env) * tk.A + a;
+    const long tile = q >> 5;
+    const int jj = (int)(q & 31);
+    float dm[NO], dsl[NO], th[NO], ep[NO];
+    float lp = 0.0f, ent = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      dm[o] = dsl[o] = th[o] = ep[o] = 0.0f;
+      if (o < tk.no) {
+        const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
+        const tn::LogProb l = tn::log_prob(tk.action_f[er * tk.no + o], mean, sc[o]);
+        lp += l.lp;
+        dm[o] = l.dmean;
+        dsl[o] = l.dscale;
+        ep[o] = tn::noise(tk.row_offset + (uint32_t)er, tk.ent_step, o, tn::STREAM_ENTROPY, tk.seed_lo, tk.seed_hi);
+        const float x = fmaf(sc[o], ep[o], mean);
+        th[o] = tanhf(x);
+        ent += 0.5f + tn::HALF_LOG_2PI + logf(sc[o]) + tn::tanh_fldj(x);
+      }
+    }
+    const float gae = (tk.f1[er] - st[0]) * st[1];
+    const float ratio = expf(lp - tk.f0[er]);
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float l1 = ratio * gae, l2 = rc * gae;
+    const bool inside = (ratio >= lo) && (ratio <= hi);
+    const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+    const float g2 = inside ? (1.0f - g1) : 0.0f;
+    const float dlp = -(g1 + g2) * gae * ratio * invR;
+    const float ec = tk.coef * invR;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      if (o < tk.no) {
+        tk.dy[(tile * tk.no + o) * 32 + jj] = dlp * dm[o] + ec * 2.0f * th[o];
+        ds[o] += dlp * dsl[o] - ec * (1.0f / sc[o] - 2.0f * th[o] * ep[o]);
+      }
+    }
+    la += -fminf(l1, l2) * invR;
+    lb += ent * invR;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    la += __shfl_down(la, o, 64);
+    lb += __shfl_down(lb, o, 64);
+#pragma unroll
+    for (int k = 0; k < NO; ++k) ds[k] += __shfl_down(ds[k], o, 64);
+  }
+  if (lane == 0) {
+    red[0][w] = la;
+    red[1][w] = lb;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) red[2 + k][w] = ds[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) tk.loss_partials[2 * blockIdx.x + threadIdx.x] =
+      ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+  if ((int)threadIdx.x < tk.no) {
+    const int k = threadIdx.x;  // d scale / d log_std = sigmoid(log_std)
+    tk.dscale_partials[(long)blockIdx.x * tk.no + k] =
+        (((red[2 + k][0] + red[2 + k][1]) + red[2 + k][2]) + red[2 + k][3]) * tn::sigmoid(tk.log_std[k]);
+  }
+}
+
+// Rollout epilogue of the continuous head: T32 means of ONE step -> tanh(loc + scale * noise) and its log-prob.
+template <int NO>
+__global__ __launch_bounds__(256) void seq_sample_cont_kernel(SeqLossTask tk) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= tk.Rm) return;
+  const long tile = q >> 5;
+  const int jj = q & 31;
+  const uint32_t gid = tk.row_offset + (uint32_t)q;
+  float lp = 0.0f;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    if (o < tk.no) {
+      const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
+      const float sc = tn::scale_of(tk.log_std[o]);
+      const float eps = tk.greedy ? 0.0f : tn::noise(gid, tk.step, o, tn::STREAM_SAMPLE, tk.seed_lo, tk.seed_hi);
+      const float a = tanhf(fmaf(sc, eps, mean));
+      lp += tn::log_prob(a, mean, sc).lp;
+      tk.action_f_out[(long)q * tk.no + o] = a;
+    }
+  }
+  tk.logp_out[q] = lp;
+}
+
 __global__ __launch_bounds__(256) void t32_to_rows_kernel(const float* __restrict__ src, int N, int rows,
                                                           float* __restrict__ dst) {
   // dst[row][f] (row-major) <- T32 src ; one thread per element, reads coalesced along rows
@@ -486,6 +608,46 @@ extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_action
   if (n_actions <= 8) hipLaunchKernelGGL((seq_loss_kernel<8, true>), dim3(n_blocks), dim3(256), 0, s, tk);
   else if (n_actions <= 16) hipLaunchKernelGGL((seq_loss_kernel<16, true>), dim3(n_blocks), dim3(256), 0, s, tk);
   else hipLaunchKernelGGL((seq_loss_kernel<32, true>), dim3(n_blocks), dim3(256), 0, s, tk);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
+                                                  const float* mean, const float* log_std, const float* action,
+                                                  const float* old_log_prob, const float* advantages,
+                                                  const double* adv_stats, int n_stats, float clip_eps, float ent_coef,
+                                                  uint64_t seed, uint32_t ent_step, uint32_t row_offset, float* dmean,
+                                                  float* loss_partials, float* dscale_partials, int n_blocks,
+                                                  hipStream_t s) {
+  MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && action_dim >= 1 && action_dim <= 16 && n_blocks >= 1, 0,
+                 "mava_seq_actor_loss_continuous_f32: bad shape (action_dim <= 16)");
+  MAVA_ARG_CHECK(mean && log_std && action && old_log_prob && advantages && adv_stats && dmean && loss_partials &&
+                 dscale_partials, 1, "mava_seq_actor_loss_continuous_f32: null pointer argument");
+  SeqLossTask tk = {};
+  tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.no = action_dim; tk.idx = idx; tk.y = mean; tk.dy = dmean;
+  tk.log_std = log_std; tk.action_f = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
+  tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = ent_coef; tk.loss_partials = loss_partials;
+  tk.dscale_partials = dscale_partials; tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32);
+  tk.ent_step = ent_step; tk.row_offset = row_offset;
+  if (action_dim <= 8) hipLaunchKernelGGL((seq_loss_cont_kernel<8>), dim3(n_blocks), dim3(256), 0, s, tk);
+  else hipLaunchKernelGGL((seq_loss_cont_kernel<16>), dim3(n_blocks), dim3(256), 0, s, tk);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std,
+                                              uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                                              float* action, float* log_prob, hipStream_t s) {
+  MAVA_ARG_CHECK(rows >= 1 && rows % 32 == 0 && action_dim >= 1 && action_dim <= 16, 0,
+                 "mava_seq_sample_continuous_f32: rows=%d action_dim=%d", rows, action_dim);
+  MAVA_ARG_CHECK(mean && log_std && action && log_prob, 1, "mava_seq_sample_continuous_f32: null pointer argument");
+  SeqLossTask tk = {};
+  tk.Rm = rows; tk.no = action_dim; tk.y = mean; tk.log_std = log_std; tk.seed_lo = (uint32_t)seed;
+  tk.seed_hi = (uint32_t)(seed >> 32); tk.step = step; tk.row_offset = row_offset; tk.greedy = greedy;
+  tk.action_f_out = action; tk.logp_out = log_prob;
+  const int blocks = mava_cdiv(rows, 256);
+  if (action_dim <= 8) hipLaunchKernelGGL((seq_sample_cont_kernel<8>), dim3(blocks), dim3(256), 0, s, tk);
+  else hipLaunchKernelGGL((seq_sample_cont_kernel<16>), dim3(blocks), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

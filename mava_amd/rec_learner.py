@@ -25,15 +25,15 @@ import torch
 from . import ops, parallel
 from ._lib import check, lib, ptr, stream_ptr
 from .learner import NUM_CU, _Replica
-from .networks import DiscreteActionHead, MLPTorso
+from .networks import MLPTorso, make_action_head
 from .rec_networks import H, RecurrentActor, RecurrentValueNet, RecWorkspace, rows_to_t32, t32_to_rows
 from .types import (AdamState, ExperimentOutput, HiddenStates, Observation, ObservationGlobalState, OptStates, Params,
                     RNNLearnerState, TimeStep)
 
 
 class _RecReplica(_Replica):
-    def __init__(self, env, T, n_upd, central, device):
-        super().__init__(env, T, n_upd, central, device)
+    def __init__(self, env, T, n_upd, central, device, continuous: bool = False):
+        super().__init__(env, T, n_upd, central, device, continuous)
         E, A = env.num_envs, env.num_agents
         EA = E * A
         if EA % 32:
@@ -84,9 +84,12 @@ class RecLearner:
         if centralised_critic and not getattr(env, "add_global_state", False):
             raise ValueError("Global state must be provided to the centralised critic.")  # networks.py:315-316
         self.reps: List[_RecReplica] = []
+        # rec_mappo.py:361-363: the action head of the configuration, sized by the env's action dimension
+        action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
+        self.continuous = type(action_head).__name__ == "ContinuousActionHead"
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
-            self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device))
+            self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
         env0 = self.reps[0].env
         self.A, self.nA = env0.num_agents, env0.action_dim
         config.system.num_agents = self.A
@@ -116,7 +119,7 @@ class RecLearner:
         mk = lambda c: MLPTorso(**{k: v for k, v in c.items() if k != "_target_"})
         hsd = int(net.get("hidden_state_dim", 128))
         self.actor_network = RecurrentActor(mk(net.actor_network.pre_torso), mk(net.actor_network.post_torso),
-                                            DiscreteActionHead(self.nA), self.Oa, hsd)
+                                            action_head, self.Oa, hsd)
         self.critic_network = RecurrentValueNet(mk(net.critic_network.pre_torso), mk(net.critic_network.post_torso),
                                                 centralised_critic, self.Oc, hsd)
         for t in (net.actor_network.pre_torso, net.actor_network.post_torso, net.critic_network.pre_torso,
@@ -141,6 +144,8 @@ class RecLearner:
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
         self.perm_gen = torch.Generator(device=d)
         self.t_global = 0
+        self.ent_step = 0  # minibatches trained so far: counter of the continuous head's entropy sample
+        self.dscale_partials = torch.zeros((self.ws.loss_partials.shape[0], max(self.nA, 1)), device=d)
         self.seed = int(s.seed)
         self._t_range = torch.arange(self.T, device=d, dtype=torch.int64)[:, None] * self.E
 
@@ -159,6 +164,7 @@ class RecLearner:
             rep.h_actor.zero_()    # ScannedRNN.initialize_carry: zeros (:497-502)
             rep.h_critic.zero_()
         self.t_global = 0
+        self.ent_step = 0
         self.perm_gen.manual_seed(self.seed)
 
     # ---------------------------------------------------------------------------- state views
@@ -201,7 +207,9 @@ class RecLearner:
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
             rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
-        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0"
+        # the fused acting step (mava_rec_step_f32) carries the categorical head; the continuous head takes the
+        # layer-wise step with its own sampling epilogue
+        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0" and not self.continuous
         for t in range(self.T):
             step = self.t_global + t
             for u, rep in enumerate(self.reps):
@@ -233,9 +241,15 @@ class RecLearner:
                 self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E,
                                                     A, training=False)
                 rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
-                check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
-                                                step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
-                                                ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
+                if self.continuous:
+                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, ptr(ws.y), ptr(self.actor_network.log_std(pa)),
+                                                               self.seed & (2**64 - 1), step & 0xFFFFFFFF,
+                                                               ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]),
+                                                               ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_continuous_f32")
+                else:
+                    check(lib().mava_seq_sample_f32(EA, self.nA, ptr(ws.y), ptr(rep.action_mask[t]), self.seed & (2**64 - 1),
+                                                    step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0,
+                                                    ptr(rep.action[t]), ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_f32")
                 # critic: a (rows x 1) T32 matrix IS row-major, so the head writes straight into the value slot
                 if self.critic_agg:  # once per env, value broadcast to the A agent slots
                     self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), 1, rep.done_env_in[t : t + 1],
@@ -296,9 +310,18 @@ class RecLearner:
             self.actor_network.forward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, rep.h0_actor, False, idx, T, Rm, E, A,
                                                 training=True)
             ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
-            check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
-                                            ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps),
-                                            float(s.ent_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st), "mava_seq_actor_loss_f32")
+            if self.continuous:
+                check(L.mava_seq_actor_loss_continuous_f32(
+                    T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), ptr(rep.action),
+                    ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
+                    self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
+                    ptr(ws.dy), ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
+                ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
+            else:
+                check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
+                                                ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0],
+                                                float(s.clip_eps), float(s.ent_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st),
+                      "mava_seq_actor_loss_f32")
             ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
             self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, self.slabs,
                                                  self.g[: self.Pa], accumulate=acc)
@@ -322,6 +345,7 @@ class RecLearner:
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
                       num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
                       ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
+        self.ent_step += 1
 
     def update(self, n: int, permutations: Optional[List[torch.Tensor]] = None) -> None:
         self._rollout(n)

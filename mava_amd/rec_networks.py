@@ -22,7 +22,7 @@ import torch
 from . import ops
 from ._lib import check, lib, ptr, stream_ptr
 from .distributions import Categorical
-from .networks import DiscreteActionHead, MLPTorso, _orthogonal_
+from .networks import ContinuousActionHead, DiscreteActionHead, MLPTorso, _orthogonal_
 
 H = 128
 G3 = 3 * H
@@ -58,6 +58,7 @@ class _RecurrentNet:
             raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
         self.din, self.n_out = int(din), int(n_out)
         self.segments, self.num_params = rec_segments(self.din, self.n_out)
+        self.num_net_params = self.num_params  # the continuous actor appends log_std(n_out) behind the network
         self.off = {n: (o, s) for n, s, o in self.segments}
 
     def seg(self, flat: torch.Tensor, name: str) -> torch.Tensor:
@@ -104,7 +105,10 @@ class _RecurrentNet:
         taken, like unreplicate_n_dims, mava/utils/jax_utils.py:52-59) into the flat layout the kernels read."""
         p = tree["params"]
         cell = p["ScannedRNN_0"]["GRUCell_0"]
-        head = p["action_head"]["Dense_0"] if "action_head" in p else p["Dense_0"]
+        if "action_head" in p:  # discrete: Dense_0 (networks.py:106); continuous: mean + log_std (networks.py:138-141)
+            head = p["action_head"]["mean"] if "mean" in p["action_head"] else p["action_head"]["Dense_0"]
+        else:
+            head = p["Dense_0"]
 
         def leaf(v, shape):
             v = torch.as_tensor(v)
@@ -125,6 +129,8 @@ class _RecurrentNet:
         self.seg(flat, "bpost").copy_(leaf(p["post_torso"]["Dense_0"]["bias"], (H,)))
         self.seg(flat, "Whead").copy_(leaf(head["kernel"], (H, self.n_out)))
         self.seg(flat, "bhead").copy_(leaf(head["bias"], (self.n_out,)))
+        if "action_head" in p and "log_std" in p["action_head"]:
+            flat[self.num_net_params : self.num_net_params + self.n_out].copy_(leaf(p["action_head"]["log_std"], (self.n_out,)))
         return flat
 
     def _apply_sequence(self, params: Any, hstate: torch.Tensor, x: torch.Tensor, done: torch.Tensor):
@@ -225,24 +231,41 @@ class _RecurrentNet:
 
 
 class RecurrentActor(_RecurrentNet):
-    """mava/networks.py:269-294 with DiscreteActionHead (head init orthogonal(0.01))."""
+    """mava/networks.py:269-294 with DiscreteActionHead or ContinuousActionHead (head init orthogonal(0.01); the
+    continuous head's log_std vector, zeros, follows the network in the flat parameters)."""
 
     head_scale = 0.01
 
-    def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head: DiscreteActionHead, obs_dim: int,
+    def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head, obs_dim: int,
                  hidden_state_dim: int = 128):
         super().__init__(obs_dim, action_head.action_dim, hidden_state_dim)
+        self.continuous = isinstance(action_head, ContinuousActionHead)
+        if self.continuous:
+            self.num_params += self.n_out
+
+    def log_std(self, flat: torch.Tensor) -> torch.Tensor:
+        return flat[self.num_net_params : self.num_net_params + self.n_out]
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        out = super().tree(flat, lead)
+        if self.continuous:
+            ls = self.log_std(flat)
+            out["params"]["action_head"]["log_std"] = ls.expand(*lead, self.n_out) if lead else ls
+        return out
 
     def _head_tree(self, head):
-        return {"action_head": {"Dense_0": head}}
+        return {"action_head": {("mean" if self.continuous else "Dense_0"): head}}
 
     def apply(self, params: Any, hstate: torch.Tensor, observation_done) -> Tuple[torch.Tensor, Any]:
         """actor_network.apply(params, hstate, (observation, done)) -> (hstate, distribution) with a leading
         time axis on observation and done (mava/networks.py:277-294; call site mava/evaluator.py:198-207)."""
-        from .distributions import Categorical
+        from .distributions import Categorical, TanhNormal
 
         observation, done = observation_done
-        h, logits = self._apply_sequence(params, hstate, observation.agents_view, done)
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        h, logits = self._apply_sequence(flat, hstate, observation.agents_view, done)
+        if self.continuous:
+            return h, TanhNormal(logits, self.log_std(flat.float()))
         return h, Categorical(logits, observation.action_mask)
 
 

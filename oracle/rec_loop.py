@@ -15,12 +15,16 @@ import numpy as np
 from . import philox
 from . import ppo_oracle as po
 from . import rec_oracle as ro
+from . import tanh_normal as tn
 from .synth_env import SynthRware
 
 
 class OracleRecLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95, clip_eps=0.2,
-                 ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4, time_limit=500, state_dim=0):
+                 ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4, time_limit=500, state_dim=0,
+                 continuous=False):
+        self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
+        self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U = E, A, O, nA, T, K, M, U
         self.centralised, self.seed = centralised, seed
         self.h = dict(gamma=gamma, lam=gae_lambda, clip=clip_eps, ent=ent_coef, vf=vf_coef, mgn=max_grad_norm, lrs=(actor_lr, critic_lr))
@@ -53,13 +57,21 @@ class OracleRecLearner:
             step = self.t_global + t
             av, cx, mask = obs["agents_view"].astype(np.float64), self._cx(obs), obs["action_mask"]
             d_in = self.dones[u].reshape(E * A)
-            y, _, self.ha[u] = ro.rec_forward(self.pa, self.Oa, nA, av.reshape(1, E * A, -1), d_in[None], self.ha[u])
-            z = po.masked_logits(y[0], mask.reshape(E * A, nA))
-            action = po.gumbel_argmax(z, philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=u * E * A))
-            lp = po.log_softmax(z)[np.arange(E * A), action]
+            n_net = ro.rec_param_count(self.Oa, nA)
+            y, _, self.ha[u] = ro.rec_forward(self.pa[:n_net], self.Oa, nA, av.reshape(1, E * A, -1), d_in[None], self.ha[u])
+            if self.continuous:
+                eps = tn.normal_noise(self.seed, step, E * A, nA, tn.STREAM_SAMPLE, row_offset=u * E * A)
+                action = tn.sample(y[0], self.pa[n_net:], eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
+                lp = tn.log_prob(action, y[0], self.pa[n_net:])
+                action = action.reshape(E, A, nA)
+            else:
+                z = po.masked_logits(y[0], mask.reshape(E * A, nA))
+                action = po.gumbel_argmax(z, philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=u * E * A))
+                lp = po.log_softmax(z)[np.arange(E * A), action]
+                action = action.reshape(E, A)
             v, _, self.hc[u] = ro.rec_forward(self.pc, self.Oc, 1, cx.reshape(1, E * A, -1), d_in[None], self.hc[u])
             obs, reward, done, info = env.step(step + 1)
-            for k, val in (("av", av), ("cx", cx), ("mask", mask), ("action", action.reshape(E, A)), ("value", v[0, :, 0].reshape(E, A)),
+            for k, val in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", v[0, :, 0].reshape(E, A)),
                            ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done_in", self.dones[u].copy()),
                            ("ret", info["episode_return"]), ("len", info["episode_length"]), ("term", info["is_terminal_step"])):
                 tr[k].append(val)
@@ -84,12 +96,22 @@ class OracleRecLearner:
             for mb in range(M):
                 envs = permutations[k][mb * Em : (mb + 1) * Em]
                 ga, gc, info = np.zeros_like(self.pa), np.zeros_like(self.pc), np.zeros(3)
-                for tr in trajs:
+                for u, tr in enumerate(trajs):
                     sel = lambda x: x[:, envs].reshape((T, Em * A) + x.shape[3:])
                     h0a = tr["h0a"].reshape(E, A, 128)[envs].reshape(Em * A, 128)
                     h0c = tr["h0c"].reshape(E, A, 128)[envs].reshape(Em * A, 128)
-                    _, la, ent, g1 = ro.rec_actor_loss_grad(self.pa, self.Oa, nA, sel(tr["av"]), sel(tr["done_in"]), h0a, sel(tr["mask"]),
-                                                            sel(tr["action"]), sel(tr["log_prob"]), sel(tr["adv"]), h["clip"], h["ent"])
+                    if self.continuous:
+                        # trajectory rows (t*E + env)*A + a of the minibatch, time-major like sel()
+                        gid = ((np.arange(T)[:, None, None] * E + np.asarray(envs)[None, :, None]) * A + np.arange(A)[None, None, :]).reshape(-1)
+                        eps = tn.normal_noise(self.seed, self.ent_step, 0, nA, tn.STREAM_ENTROPY, row_offset=u * T * E * A,
+                                              gid=gid).astype(np.float64).reshape(T, Em * A, nA)
+                        _, la, ent, g1 = ro.rec_actor_loss_grad_continuous(
+                            self.pa, self.Oa, nA, sel(tr["av"]), sel(tr["done_in"]), h0a, sel(tr["action"]), sel(tr["log_prob"]),
+                            sel(tr["adv"]), h["clip"], h["ent"], eps)
+                    else:
+                        _, la, ent, g1 = ro.rec_actor_loss_grad(self.pa, self.Oa, nA, sel(tr["av"]), sel(tr["done_in"]), h0a,
+                                                                sel(tr["mask"]), sel(tr["action"]), sel(tr["log_prob"]),
+                                                                sel(tr["adv"]), h["clip"], h["ent"])
                     _, vl, g2 = ro.rec_critic_loss_grad(self.pc, self.Oc, sel(tr["cx"]), sel(tr["done_in"]), h0c, sel(tr["value"]),
                                                         sel(tr["tgt"]), h["clip"], h["vf"])
                     ga += g1
@@ -100,4 +122,5 @@ class OracleRecLearner:
                 self.pc, self.mc, self.vc, self.counts[1] = po.clip_adam(self.pc, gc, self.mc, self.vc, self.counts[1], h["lrs"][1], h["mgn"])
                 la, ent, vl = info
                 metrics[k, mb] = [(la - h["ent"] * ent) + h["vf"] * vl, vl, la, ent]
+                self.ent_step += 1
         return {"train_metrics": metrics}

@@ -135,6 +135,45 @@ def rec_actor_loss_grad(flat, din, no, obs, done, h0, mask, action, old_log_prob
     return float(total.detach()), float(loss_actor.detach()), float(entropy.detach()), f.grad.numpy()
 
 
+def t_tanh_normal_log_prob(action: torch.Tensor, mean: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """Joint log-density of Independent(TanhTransformed(Normal(mean, scale))) in torch (autograd), the formulas of
+    oracle/tanh_normal.py written independently: distributions.py:24-91."""
+    import math
+
+    th, ath, log_eps = 0.999, math.atanh(0.999), math.log(1.0 - 0.999)
+    yc = action.clamp(-th, th)
+    left, right = yc <= -th, yc >= th
+    x = torch.atanh(torch.where(left | right, torch.zeros_like(yc), yc))
+    inner = (-0.5 * ((x - mean) / scale) ** 2 - torch.log(scale) - 0.5 * math.log(2 * math.pi)
+             - 2.0 * (math.log(2.0) - x - torch.nn.functional.softplus(-2.0 * x)))
+    lcdf = torch.special.log_ndtr((-ath - mean) / scale) - log_eps
+    lsf = torch.special.log_ndtr((mean - ath) / scale) - log_eps
+    return torch.where(left, lcdf, torch.where(right, lsf, inner)).sum(-1)
+
+
+def rec_actor_loss_grad_continuous(flat, din, dim, obs, done, h0, action, old_log_prob, gae, clip_eps, ent_coef, eps):
+    """rec_mappo.py:210-242 with ContinuousActionHead (networks.py:127-169): flat = [recurrent network | log_std(dim)],
+    action (T,R,dim), eps (T,R,dim) the entropy noise.  Returns (total, loss_actor, entropy, flat grad) in float64."""
+    import math
+
+    f = torch.tensor(np.asarray(flat, np.float64), requires_grad=True)
+    tt = lambda a, dt=torch.float64: torch.tensor(np.asarray(a), dtype=dt)
+    n_net = rec_param_count(din, dim)
+    mean, _ = t_rec_forward(f[:n_net], din, dim, tt(obs), tt(done, torch.bool), tt(h0))
+    scale = torch.nn.functional.softplus(f[n_net:]) + 1e-3
+    lp = t_tanh_normal_log_prob(tt(action), mean, scale)
+    ratio = torch.exp(lp - tt(old_log_prob))
+    g = tt(gae)
+    g = (g - g.mean()) / (g.std(unbiased=False) + 1e-8)
+    loss_actor = -torch.minimum(ratio * g, torch.clamp(ratio, 1 - clip_eps, 1 + clip_eps) * g).mean()
+    x = mean + scale * tt(eps)
+    fldj = 2.0 * (math.log(2.0) - x - torch.nn.functional.softplus(-2.0 * x))
+    entropy = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(scale) + fldj).sum(-1).mean()
+    total = loss_actor - ent_coef * entropy
+    total.backward()
+    return float(total.detach()), float(loss_actor.detach()), float(entropy.detach()), f.grad.numpy()
+
+
 def rec_critic_loss_grad(flat, din, x, done, h0, old_value, targets, clip_eps, vf_coef):
     """rec_mappo.py:244-266.  Returns (total, value_loss, flat grad)."""
     f = torch.tensor(np.asarray(flat, np.float64), requires_grad=True)

@@ -187,3 +187,68 @@ def test_continuous_learner_update_matches_oracle(dev, system, U):
     ev = get_eval_fn(eval_env, make_ff_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
     m = ev(out.learner_state.params.actor_params, 0)
     assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes
+
+
+@pytest.mark.parametrize("system,U,E", [("rec_mappo", 1, 16), ("rec_ippo", 2, 16), ("rec_mappo", 1, 64)])
+def test_continuous_rec_learner_update_matches_oracle(dev, system, U, E):
+    """The recurrent systems with network.action_head = ContinuousActionHead against the whole-update oracle (BPTT
+    gradients from torch autograd in float64, distribution formulas written independently of oracle/tanh_normal.py)."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_ippo, rec_mappo
+    from oracle import rec_oracle as ro
+    from oracle.rec_loop import OracleRecLearner
+
+    A, O, dim, T, K, M = 4, 10, 3, 6, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}",
+                                        "network.action_head._target_=mava.networks.ContinuousActionHead"])
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": dim}
+    cfg.env.kwargs.time_limit = 4
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    central = system == "rec_mappo"
+    mod = rec_mappo if central else rec_ippo
+    env, eval_env = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    assert L.continuous and L.reps[0].action.shape == (T, E, A, dim)
+    head = state.params.actor_params["params"]["action_head"]
+    assert head["mean"]["kernel"].shape == (1, U, 128, dim) and head["log_std"].shape == (1, U, dim)
+
+    rng = np.random.default_rng(1)
+    Oc = A * O if central else A + O
+    fa = np.concatenate([ro.init_rec(rng, A + O, dim, 1.0), rng.normal(size=dim) * 0.3]).astype(np.float32)
+    fc = ro.init_rec(rng, Oc, 1, 1.0).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleRecLearner(E=E, A=A, O=O, nA=dim, T=T, K=K, M=M, U=U, centralised=central, seed=42, actor_lr=1e-3,
+                           critic_lr=2e-3, time_limit=4, continuous=True)
+    ora.set_params(fa, fc)
+    for n in range(2):
+        perms = [rng.permutation(E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[u]
+            assert_close(rep.action.cpu().numpy(), tr["action"], 1e-5, "actions", scale=1.0)
+            assert np.array_equal(rep.done_in.cpu().numpy().astype(bool), tr["done_in"]) and tr["done_in"].any()
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-4, "log_probs", scale=1.0)
+            assert_close(rep.value.cpu().numpy(), tr["value"], 1e-5, "values")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], 1e-5, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
+        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+    # learn() round trip and the recurrent evaluator seam with the continuous distribution view
+    out = learn(L.learner_state())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()
+    from mava_amd.evaluator import get_eval_fn, make_rec_eval_act_fn
+
+    ev = get_eval_fn(eval_env, make_rec_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
+    init = {"hidden_state": torch.zeros((eval_env.num_envs, A, 128), device=dev)}
+    m = ev(out.learner_state.params.actor_params, 0, init)
+    assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes

@@ -293,3 +293,27 @@ def test_continuous_actor_gradient_finite_difference():
         e[i] = 1e-6
         fd = (f(flat + e)[0] - f(flat - e)[0]) / 2e-6
         assert abs(fd - g[i]) <= 1e-5 * max(1.0, abs(g[i])), (i, fd, g[i])
+
+
+def test_continuous_head_numpy_vs_torch_autograd():
+    """Two independent restatements of the continuous head agree: oracle/tanh_normal.py (NumPy, hand-derived gradients)
+    and the torch-autograd formulas in oracle/rec_oracle.py (torch.special.log_ndtr, softplus, atanh)."""
+    import torch
+
+    from oracle import rec_oracle as ro
+    from oracle import tanh_normal as tn
+
+    rng = np.random.default_rng(3)
+    R, dim = 40, 4
+    mean, ls = rng.normal(size=(R, dim)), rng.normal(size=dim) * 0.4
+    a = np.tanh(mean + tn.scale_of(ls) * rng.normal(size=(R, dim)))
+    a[0, 0], a[1, 1], a[2, 2] = 0.9999, -1.0, 0.999
+    m_t = torch.tensor(mean, requires_grad=True)
+    ls_t = torch.tensor(ls, requires_grad=True)
+    lp_t = ro.t_tanh_normal_log_prob(torch.tensor(a), m_t, torch.nn.functional.softplus(ls_t) + 1e-3)
+    np.testing.assert_allclose(lp_t.detach().numpy(), tn.log_prob(a, mean, ls), rtol=1e-9, atol=1e-9)
+    w = rng.normal(size=R)
+    (lp_t * torch.tensor(w)).sum().backward()
+    _, dmean, dscale = tn.log_prob_terms(a, mean, tn.scale_of(ls))
+    np.testing.assert_allclose(m_t.grad.numpy(), w[:, None] * dmean, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(ls_t.grad.numpy(), (w[:, None] * dscale).sum(0) * tn.sigmoid(ls), rtol=1e-7, atol=1e-10)

@@ -29,6 +29,14 @@ def test_overrides():
     assert c.system.num_agents == 4
     with pytest.raises(ValueError):
         compose("default_ff_isac")
+    # network group swap like the reference's `network=continuous_mlp` (configs/network/continuous_mlp.yaml)
+    from mava_amd.networks import ContinuousActionHead, DiscreteActionHead, make_action_head
+
+    assert isinstance(make_action_head(compose("default_ff_mappo", ["network=continuous_mlp"]).network.action_head, 3),
+                      ContinuousActionHead)
+    assert isinstance(make_action_head(c.network.action_head, 5), DiscreteActionHead)
+    with pytest.raises(NotImplementedError):
+        ContinuousActionHead(3, independent_std=False)
 
 
 def test_total_timesteps():

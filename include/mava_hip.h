@@ -254,6 +254,15 @@ int mava_rec_step_f32(const float* actor_params, int actor_din, int n_actions, c
                       const float* critic_input, int critic_share, const uint8_t* done_c, int done_c_stride,
                       const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
                       float* value, mava_stream_t s);
+/* the same fused acting step with ContinuousActionHead: actor_params = [recurrent network | log_std(action_dim)],
+ * action (rows_a, action_dim) float = tanh(loc + scale * noise) (noise stream of mava_seq_sample_continuous_f32). */
+int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim, const float* agents_view,
+                                 const uint8_t* done_a, const float* h_actor_in, float* h_actor_out, int rows_a,
+                                 uint64_t seed, uint32_t step, uint32_t row_offset, int greedy, float* action,
+                                 float* log_prob, const float* critic_params, int critic_din,
+                                 const float* critic_input, int critic_share, const uint8_t* done_c, int done_c_stride,
+                                 const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                                 float* value, mava_stream_t s);
 
 /* T32 <-> row-major conversion of a (rows x N) matrix. */
 int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);

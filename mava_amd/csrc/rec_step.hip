@@ -14,6 +14,7 @@
 // through [feature][row] LDS tiles (stride 33).  Blocks [0, nblk_actor) serve the actor, the rest the critic - e.g.
 // one critic sequence per ENV when the agents share the critic input - so both networks share one launch.
 #include "mlp_core.h"
+#include "tanh_normal.h"
 
 namespace {
 
@@ -40,6 +41,7 @@ struct RecStepOut {
   float* log_prob;
   float* value;          // (rows_c * vbroadcast)
   int vbroadcast;
+  float* action_f;       // continuous head (tanh_normal.h) when not null: (rows, no) actions; log_std follows bhead
 };
 
 __device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
@@ -221,6 +223,22 @@ __device__ __forceinline__ void rec_step_body(const RecNet& nt, const RecStepOut
                 YP[(3 * NO + o) * 32 + j]) + ((o < no) ? bhead[o] : 0.0f);
       if (!ACTOR) {
         for (int b = 0; b < out.vbroadcast; ++b) out.value[(long)row * out.vbroadcast + b] = y[0];
+      } else if (out.action_f != nullptr) {
+        // ContinuousActionHead (networks.py:127-169): same noise stream as mava_seq_sample_continuous_f32
+        const float* const log_std = bhead + no;
+        const uint32_t gid = out.row_offset + (uint32_t)row;
+        float lp = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          if (o < no) {
+            const float sc = tn::scale_of(log_std[o]);
+            const float eps = out.greedy ? 0.0f : tn::noise(gid, out.step, o, tn::STREAM_SAMPLE, out.seed_lo, out.seed_hi);
+            const float a = tanhf(fmaf(sc, eps, y[o]));
+            lp += tn::log_prob(a, y[o], sc).lp;
+            out.action_f[(long)row * no + o] = a;
+          }
+        }
+        out.log_prob[row] = lp;
       } else {
         Categorical<NO> cat;
         cat.build(y, out.mask != nullptr ? (out.mask + (long)row * no) : nullptr, no);
@@ -284,18 +302,19 @@ void carve(RecNet& n, int no_pad) {
 
 }  // namespace
 
-extern "C" int mava_rec_step_f32(const float* actor_params, int actor_din, int n_actions, const float* agents_view,
-                                 const uint8_t* action_mask, const uint8_t* done_a, const float* h_actor_in,
-                                 float* h_actor_out, int rows_a, uint64_t seed, uint32_t step, uint32_t row_offset,
-                                 int greedy, int32_t* action, float* log_prob, const float* critic_params,
-                                 int critic_din, const float* critic_input, int critic_share, const uint8_t* done_c,
-                                 int done_c_stride, const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
-                                 float* value, hipStream_t s) {
+// Both entry points; action_f != nullptr selects the continuous head (action / action_mask unused then).
+static int rec_step_impl(const float* actor_params, int actor_din, int n_actions, const float* agents_view,
+                         const uint8_t* action_mask, const uint8_t* done_a, const float* h_actor_in,
+                         float* h_actor_out, int rows_a, uint64_t seed, uint32_t step, uint32_t row_offset,
+                         int greedy, int32_t* action, float* action_f, float* log_prob, const float* critic_params,
+                         int critic_din, const float* critic_input, int critic_share, const uint8_t* done_c,
+                         int done_c_stride, const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                         float* value, hipStream_t s) {
   MAVA_ARG_CHECK(rows_a >= 0 && rows_c >= 0 && rows_a % 32 == 0 && rows_c % 32 == 0, 0,
                  "mava_rec_step_f32: rows must be multiples of 32 (rows_a=%d rows_c=%d)", rows_a, rows_c);
   if (rows_a == 0 && rows_c == 0) return MAVA_OK;
   MAVA_ARG_CHECK(rows_a == 0 || (actor_din >= 1 && n_actions >= 1 && n_actions <= 32 && actor_params && agents_view &&
-                                 done_a && h_actor_in && h_actor_out && action && log_prob),
+                                 done_a && h_actor_in && h_actor_out && (action || action_f) && log_prob),
                  1, "mava_rec_step_f32: bad actor arguments");
   MAVA_ARG_CHECK(rows_c == 0 || (critic_din >= 1 && critic_share >= 1 && value_broadcast >= 1 && done_c_stride >= 1 && critic_params &&
                                  critic_input && done_c && h_critic_in && h_critic_out && value),
@@ -317,6 +336,7 @@ extern "C" int mava_rec_step_f32(const float* actor_params, int actor_din, int n
   so.mask = action_mask; so.seed_lo = (uint32_t)seed; so.seed_hi = (uint32_t)(seed >> 32); so.step = step;
   so.row_offset = row_offset; so.greedy = greedy; so.action = action; so.log_prob = log_prob; so.value = value;
   so.vbroadcast = value_broadcast;
+  so.action_f = action_f;
   const int ta = rows_a / 32, tc = rows_c / 32;
   // one block per CU; the CUs are shared out in proportion to the tiles of the two networks
   int nba = ta, nbc = tc;
@@ -344,4 +364,31 @@ extern "C" int mava_rec_step_f32(const float* actor_params, int actor_din, int n
 #undef LAUNCH
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
+}
+
+extern "C" int mava_rec_step_f32(const float* actor_params, int actor_din, int n_actions, const float* agents_view,
+                                 const uint8_t* action_mask, const uint8_t* done_a, const float* h_actor_in,
+                                 float* h_actor_out, int rows_a, uint64_t seed, uint32_t step, uint32_t row_offset,
+                                 int greedy, int32_t* action, float* log_prob, const float* critic_params,
+                                 int critic_din, const float* critic_input, int critic_share, const uint8_t* done_c,
+                                 int done_c_stride, const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                                 float* value, hipStream_t s) {
+  return rec_step_impl(actor_params, actor_din, n_actions, agents_view, action_mask, done_a, h_actor_in, h_actor_out, rows_a,
+                       seed, step, row_offset, greedy, action, nullptr, log_prob, critic_params, critic_din, critic_input,
+                       critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s);
+}
+
+extern "C" int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+                                            const float* agents_view, const uint8_t* done_a, const float* h_actor_in,
+                                            float* h_actor_out, int rows_a, uint64_t seed, uint32_t step,
+                                            uint32_t row_offset, int greedy, float* action, float* log_prob,
+                                            const float* critic_params, int critic_din, const float* critic_input,
+                                            int critic_share, const uint8_t* done_c, int done_c_stride,
+                                            const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                                            float* value, hipStream_t s) {
+  MAVA_ARG_CHECK(action_dim <= 16 && (rows_a == 0 || action != nullptr), 1,
+                 "mava_rec_step_continuous_f32: action_dim <= 16 and a non-null action buffer are required");
+  return rec_step_impl(actor_params, actor_din, action_dim, agents_view, nullptr, done_a, h_actor_in, h_actor_out, rows_a,
+                       seed, step, row_offset, greedy, nullptr, action, log_prob, critic_params, critic_din, critic_input,
+                       critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s);
 }

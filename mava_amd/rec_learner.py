@@ -207,9 +207,7 @@ class RecLearner:
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
             rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
-        # the fused acting step (mava_rec_step_f32) carries the categorical head; the continuous head takes the
-        # layer-wise step with its own sampling epilogue
-        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0" and not self.continuous
+        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0"
         for t in range(self.T):
             step = self.t_global + t
             for u, rep in enumerate(self.reps):
@@ -220,13 +218,20 @@ class RecLearner:
                     # agent 0's flag of each env: stride A); done_in is materialised once after the rollout.
                     agg = self.critic_agg
                     d_prev = rep.dones if t == 0 else rep.done[t - 1]
-                    check(lib().mava_rec_step_f32(
-                        ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(rep.action_mask[t]), ptr(d_prev),
-                        ptr(rep.h_actor), ptr(rep.h_actor_next), EA, self.seed & (2**64 - 1), step & 0xFFFFFFFF,
-                        ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]), ptr(rep.log_prob[t]),
-                        ptr(pc), self.Oc, ptr(self._critic_x(rep, t, t + 1)), 1 if agg else self.critic_share,
-                        ptr(d_prev), A if agg else 1, ptr(rep.h_critic), ptr(rep.h_critic_next),
-                        E if agg else EA, A if agg else 1, ptr(rep.value[t]), stream_ptr()), "mava_rec_step_f32")
+                    critic_args = (ptr(pc), self.Oc, ptr(self._critic_x(rep, t, t + 1)), 1 if agg else self.critic_share,
+                                   ptr(d_prev), A if agg else 1, ptr(rep.h_critic), ptr(rep.h_critic_next),
+                                   E if agg else EA, A if agg else 1, ptr(rep.value[t]), stream_ptr())
+                    rng_args = (self.seed & (2**64 - 1), step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0)
+                    if self.continuous:
+                        check(lib().mava_rec_step_continuous_f32(
+                            ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(d_prev), ptr(rep.h_actor),
+                            ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]), *critic_args),
+                            "mava_rec_step_continuous_f32")
+                    else:
+                        check(lib().mava_rec_step_f32(
+                            ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(rep.action_mask[t]), ptr(d_prev),
+                            ptr(rep.h_actor), ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]),
+                            *critic_args), "mava_rec_step_f32")
                     rep.h_actor, rep.h_actor_next = rep.h_actor_next, rep.h_actor
                     rep.h_critic, rep.h_critic_next = rep.h_critic_next, rep.h_critic
                     rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],

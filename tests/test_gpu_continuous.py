@@ -189,8 +189,9 @@ def test_continuous_learner_update_matches_oracle(dev, system, U):
     assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes
 
 
-@pytest.mark.parametrize("system,U,E", [("rec_mappo", 1, 16), ("rec_ippo", 2, 16), ("rec_mappo", 1, 64)])
-def test_continuous_rec_learner_update_matches_oracle(dev, system, U, E):
+@pytest.mark.parametrize("system,U,E,fused", [("rec_mappo", 1, 16, "1"), ("rec_ippo", 2, 16, "0"), ("rec_mappo", 1, 64, "1"),
+                                              ("rec_mappo", 1, 64, "0")])
+def test_continuous_rec_learner_update_matches_oracle(dev, monkeypatch, system, U, E, fused):
     """The recurrent systems with network.action_head = ContinuousActionHead against the whole-update oracle (BPTT
     gradients from torch autograd in float64, distribution formulas written independently of oracle/tanh_normal.py)."""
     from mava_amd import envs
@@ -199,6 +200,8 @@ def test_continuous_rec_learner_update_matches_oracle(dev, system, U, E):
     from oracle import rec_oracle as ro
     from oracle.rec_loop import OracleRecLearner
 
+    # fused acting step (mava_rec_step_continuous_f32) or the layer-wise one (mava_seq_sample_continuous_f32)
+    monkeypatch.setenv("MAVA_REC_FUSED_STEP", fused)
     A, O, dim, T, K, M = 4, 10, 3, 6, 2, 2
     cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
                                         f"system.num_minibatches={M}", f"system.update_batch_size={U}",

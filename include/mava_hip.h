@@ -126,7 +126,7 @@ int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const f
  *
  * mava_ppo_actor_grad_continuous_f32: _actor_loss_fn ff_mappo.py:150-180 for this head; the entropy sample of
  * ff_mappo.py:176-177 is drawn from Philox(counter (row_offset + trajectory row, ent_step, dim/2), key seed).
- * slab row = [MLP gradient | d/d log_std | actor_loss, entropy]; observation width <= 127. */
+ * slab row = [MLP gradient | d/d log_std | actor_loss, entropy]. */
 int mava_policy_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
                                     const float* agents_view, const float* critic_params, int critic_din,
                                     const float* critic_input, int critic_share, int critic_rows,

@@ -941,7 +941,7 @@ int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int kt = tk.din / 32 + 1;  // 32*kt > din: the x tile always has a spare column for the ones (bias) input
 #ifdef MAVA_FAST_BUILD  // developer iteration: only the BASELINE config-2 instantiations
   if (kt == 3) return launch_xv<NO, 3, ACTOR, CONT>(tk, n_slab, s);
-  if (kt == 9 && !CONT) return launch_xv<NO, 9, ACTOR, false>(tk, n_slab, s);
+  if (kt == 9) return launch_xv<NO, 9, ACTOR, CONT>(tk, n_slab, s);
   mava_set_error("fast build: input width %d not instantiated", tk.din);
   return MAVA_EARG(9);
 #else
@@ -950,15 +950,9 @@ int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
     case 2: return launch_xv<NO, 2, ACTOR, CONT>(tk, n_slab, s);
     case 3: return launch_xv<NO, 3, ACTOR, CONT>(tk, n_slab, s);
     case 4: return launch_xv<NO, 4, ACTOR, CONT>(tk, n_slab, s);
-    default: break;
-  }
-  if (CONT) {  // the continuous head is instantiated for observation widths up to 127 (MaBrax-sized inputs)
-    mava_set_error("ppo_train (continuous head): input width %d > 127 is not instantiated", tk.din);
-    return MAVA_EARG(9);
-  }
-  switch (kt) {
-    case 5: case 6: return launch_xv<NO, 6, ACTOR, false>(tk, n_slab, s);
-    case 7: case 8: case 9: return launch_xv<NO, 9, ACTOR, false>(tk, n_slab, s);
+    // (continuous head: the wide instantiations below spill some registers - tuned shapes are the ones above)
+    case 5: case 6: return launch_xv<NO, 6, ACTOR, CONT>(tk, n_slab, s);
+    case 7: case 8: case 9: return launch_xv<NO, 9, ACTOR, CONT>(tk, n_slab, s);
     default:
       mava_set_error("ppo_train: input width %d > 287 is not instantiated", tk.din);
       return MAVA_EARG(9);

@@ -68,7 +68,7 @@ def test_continuous_policy_step_matches_oracle(dev, rows, din, dim, share):
 
 @pytest.mark.parametrize("TE,A,O,dim,Rb,use_idx,n_slab", [(64, 4, 20, 2, 64, False, 3), (200, 2, 60, 6, 77, True, 8),
                                                           (96, 3, 100, 9, 40, True, 2), (33, 1, 7, 1, 33, True, 1),
-                                                          (4096, 4, 22, 2, 2048, True, 256)])
+                                                          (4096, 4, 22, 2, 2048, True, 256), (80, 2, 180, 4, 50, True, 3)])
 def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n_slab):
     from mava_amd import ops
 
@@ -108,17 +108,19 @@ def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n
     assert_close(got[P:], np.array([la, ent]), 1e-5, "actor loss/entropy", scale=1.0)
 
 
-def test_continuous_actor_grad_rejects_wide_inputs(dev):
+def test_continuous_actor_grad_rejects_unsupported_shapes(dev):
     from mava_amd import ops
     from mava_amd._lib import MavaHipError
 
-    din, dim, TE = 200, 2, 32
-    flat = torch.zeros(ops.continuous_param_count(din, dim), device=dev)
     z = torch.zeros
-    with pytest.raises(MavaHipError, match="not instantiated"):
-        ops.ppo_actor_grad_continuous(flat, z((TE, din), device=dev), z((TE, dim), device=dev), z(TE, device=dev),
-                                      z(TE, device=dev), z((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=dev),
-                                      None, 0, TE, 1, dim, 0.2, 0.01, 1, 1, 0, z((1, flat.numel() + 2), device=dev))
+    nb = ops.lib().mava_adv_stats_blocks()
+    for din, dim, msg in ((300, 2, "not instantiated"), (264, 2, "LDS"), (20, 17, "action_dim")):
+        TE = 32
+        flat = z(ops.continuous_param_count(din, dim), device=dev)
+        with pytest.raises(MavaHipError, match=msg):
+            ops.ppo_actor_grad_continuous(flat, z((TE, din), device=dev), z((TE, dim), device=dev), z(TE, device=dev),
+                                          z(TE, device=dev), z((nb, 2), dtype=torch.float64, device=dev), None, 0, TE, 1,
+                                          dim, 0.2, 0.01, 1, 1, 0, z((1, flat.numel() + 2), device=dev))
 
 
 @pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])

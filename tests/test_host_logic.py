@@ -73,6 +73,34 @@ def test_param_tree_is_a_view_of_the_flat_buffer():
         FeedForwardActor(MLPTorso([128]), DiscreteActionHead(5), 70)
 
 
+def test_continuous_head_param_trees():
+    """ContinuousActionHead (networks.py:127-169): Flax names action_head/{mean, log_std}; log_std (zeros) follows the
+    network in the flat vector; tree <-> flat round trips for the feed-forward and the recurrent actor."""
+    from mava_amd.networks import ContinuousActionHead, FeedForwardActor, MLPTorso
+    from mava_amd.rec_networks import RecurrentActor, rec_segments
+
+    ff = FeedForwardActor(MLPTorso([128, 128]), ContinuousActionHead(3), 31)
+    assert ff.continuous and ff.num_params == ff.num_mlp_params + 3 == 31 * 128 + 128 + 128 * 128 + 128 + 128 * 3 + 3 + 3
+    flat = ff.init_flat(5)
+    assert float(flat[-3:].abs().max()) == 0.0  # nn.initializers.zeros
+    flat[-3:] = torch.tensor([0.1, -0.2, 0.3])
+    tree = ff.tree(flat, lead=(1, 2))
+    ah = tree["params"]["action_head"]
+    assert set(ah) == {"mean", "log_std"} and ah["mean"]["kernel"].shape == (1, 2, 128, 3) and ah["log_std"].shape == (1, 2, 3)
+    assert ah["log_std"].data_ptr() == flat[-3:].data_ptr()
+    assert torch.equal(ff.flat_from_tree(tree), flat)
+
+    rec = RecurrentActor(MLPTorso([128]), MLPTorso([128]), ContinuousActionHead(2), 20)
+    n_net = rec_segments(20, 2)[1]
+    assert rec.continuous and rec.num_params == n_net + 2
+    rflat = rec.init_flat(6)
+    rflat[-2:] = torch.tensor([0.5, -0.5])
+    rtree = rec.tree(rflat, lead=(1, 1))
+    assert set(rtree["params"]["action_head"]) == {"mean", "log_std"}
+    assert torch.equal(rec.flat_from_tree(rtree), rflat)
+    assert torch.equal(rec.log_std(rflat), rflat[-2:])
+
+
 def test_final_step_metrics():
     from mava_amd.learner import get_final_step_metrics
 
@@ -97,3 +125,19 @@ def test_categorical_host_view():
     assert float(d.entropy()[0]) > 0
     s = d.sample(seed=torch.Generator().manual_seed(0))
     assert int(s[0]) in (0, 1)
+
+
+def test_tanh_normal_host_view():
+    """The evaluator-seam distribution of the continuous head against the oracle formulas (distributions.py:24-91)."""
+    from mava_amd.distributions import TanhNormal
+    from oracle import tanh_normal as tn
+
+    rng = np.random.default_rng(0)
+    loc, ls = rng.normal(size=(6, 3)), rng.normal(size=3) * 0.3
+    d = TanhNormal(torch.from_numpy(loc), torch.from_numpy(ls))
+    assert torch.allclose(d.mode(), torch.tanh(torch.from_numpy(loc)))
+    a = np.tanh(loc + 0.2)
+    a[0, 0], a[1, 1] = 0.9999, -1.0
+    np.testing.assert_allclose(d.log_prob(torch.from_numpy(a)).numpy(), tn.log_prob(a, loc, ls), rtol=1e-6, atol=1e-6)
+    s = d.sample(seed=torch.Generator().manual_seed(0))
+    assert s.shape == (6, 3) and float(s.abs().max()) < 1.0 and torch.isfinite(d.entropy(seed=torch.Generator().manual_seed(1))).all()

@@ -26,7 +26,6 @@ HIP_SOURCES = [
     "rec_dense.hip",
     "rec_gru.hip",
     "rec_step.hip",
-    "engine.hip",
 ]
 CPP_SOURCES = ["api.cpp"]
 
@@ -76,7 +75,10 @@ def _compile(src: str, verbose: bool) -> str:
 
 
 def build(verbose: bool = False, jobs: int = 4) -> str:
-    srcs = [s for s in HIP_SOURCES + CPP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = HIP_SOURCES + CPP_SOURCES
+    missing = [s for s in srcs if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:
+        raise RuntimeError(f"missing sources under {CSRC}: {missing}")
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
     flags_changed = _flags_changed()

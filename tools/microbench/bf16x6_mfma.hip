@@ -33,7 +33,7 @@ constexpr int LDB = 132;   // row stride of the B tile in LDS (floats)
 // MODE 3: like 1 with the six products alternating between two accumulators (no back-to-back dependent MFMAs)
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void bench_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                                       int iters) {
+                                                       int iters, unsigned long long* __restrict__ cyc) {
   __shared__ __attribute__((aligned(16))) float BT[32 * LDB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
   for (int i = threadIdx.x; i < 32 * 128; i += 256) BT[(i >> 7) * LDB + (i & 127)] = b[i];
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256, 1) void bench_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
   const float* xb = BT + j * LDB + 8 * h;
+  const unsigned long long c0 = __builtin_readcyclecounter();   // shader-clock cycles (s_memtime)
+  const unsigned long long w0 = wall_clock64();                  // constant 100 MHz
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -87,6 +89,10 @@ __global__ __launch_bounds__(256, 1) void bench_kernel(const float* __restrict__
   // C layout: col = lane & 31 (row j of B), row = (r & 3) + 8 (r >> 2) + 4 h (feature within the block)
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cyc[0] = __builtin_readcyclecounter() - c0;
+    cyc[1] = wall_clock64() - w0;
+  }
   if (blockIdx.x == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(32 * w + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = acc[r];
@@ -95,24 +101,30 @@ __global__ __launch_bounds__(256, 1) void bench_kernel(const float* __restrict__
 
 template <int MODE>
 double run(const float* a, const float* b, float* out, int iters, const char* name, const std::vector<double>& ref, int blocks) {
+  static unsigned long long* cyc = nullptr;
+  if (!cyc) CHECK(hipMalloc(&cyc, 16));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, 1);
+  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, 1, cyc);
   CHECK(hipDeviceSynchronize());
   std::vector<float> got(128 * 32);
   CHECK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
   double err = 0, rms = 0;
   for (size_t i = 0; i < got.size(); ++i) { err = fmax(err, fabs(got[i] - ref[i])); rms += ref[i] * ref[i]; }
   rms = sqrt(rms / got.size());
-  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, iters);
+  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, iters, cyc);
   CHECK(hipEventRecord(e0));
-  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, iters);
+  hipLaunchKernelGGL(bench_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, a, b, out, iters, cyc);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double flop = 2.0 * 128 * 128 * 32 * (double)iters * blocks;  // algorithmic f32 FLOPs of the product
-  printf("%-34s %8.3f ms  %7.1f TFLOP/s (f32-equivalent)  max err / rms vs f64: %.2e\n", name, ms, flop / ms / 1e9, err / rms);
+  unsigned long long hc[2];
+  CHECK(hipMemcpy(hc, cyc, 16, hipMemcpyDeviceToHost));
+  const double n_mfma = (double)iters * KB * (MODE == 0 ? 8 : 6);
+  printf("%-34s %8.3f ms  %7.1f TFLOP/s (f32-equivalent)  max err / rms vs f64: %.2e | %.1f shader cycles per MFMA, shader clock %.2f GHz\n",
+         name, ms, flop / ms / 1e9, err / rms, hc[0] / n_mfma, hc[0] / (hc[1] * 10.0));
   return ms;
 }
 

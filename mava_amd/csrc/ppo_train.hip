@@ -198,6 +198,36 @@ __device__ __forceinline__ float group_allreduce(float v, Op op) {
   return v;
 }
 
+// f32 operand -> three bf16 terms (hi + mid + lo, round to nearest): the six products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+// lo*hi on v_mfma_f32_32x32x16_bf16 (f32 accumulation, bf16 x bf16 exact) reproduce the f32 product to f32 accuracy
+// (tools/bf16_split_study.py, tools/microbench/bf16x6_mfma.hip) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 inputs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    const float r1 = x[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    hi[i] = h; mid[i] = m; lo[i] = (__bf16)(r1 - (float)m);
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16x6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
+                                              const bf16x8& bm, const bf16x8& bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);  // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+// Pilot (off by default, -DMAVA_GW2_BF16X6=1 through MAVA_HIPCC_EXTRA): the gW2 product of P5 on this form.  Parity holds
+// (every gradient test passes), but each wave has to split all 128 features of h1^T itself - 4x redundant VALU work that the
+// 48 bf16 MFMAs do not cover: actor 1.59 vs 1.51 ms, critic 0.62 vs 0.59 ms per launch.  The form pays once every consumer of
+// an exchange tile reads it pre-split (the producer splits once), which is a new LDS layout for the whole kernel - DESIGN §9.
+#ifndef MAVA_GW2_BF16X6
+#define MAVA_GW2_BF16X6 0
+#endif
+
 template <int NO, int KT1, bool ACTOR, int XV, bool CONT>
 __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLdsLayout L) {
   static_assert(!CONT || ACTOR, "the continuous head belongs to the actor");
@@ -777,6 +807,34 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     // ---------------------------------------------------------------- P5: weight gradients
     // gW2 needs h1^T and dz2^T only, so it runs BEFORE barrier D: the dz1^T writes above drain under its MFMAs
     // instead of in front of the barrier
+#if MAVA_GW2_BF16X6
+    {
+      // gW2[k_in tile t][n = 32w + j] += sum_rows h1^T[k_in][row] * dz2^T[n][row] as bf16 x 6: MFMA m of a 32-row tile
+      // multiplies rows 16m + 8h + s (lane half h, slot s) - eight consecutive floats of a [feature][row] exchange row
+      const float* ea = H1T + j * LDT + 8 * h;
+      const float* eb = DZ2T + (32 * w + j) * LDT + 8 * h;
+      bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = eb[16 * m + s];
+        split3(v, bh[m], bm[m], bl[m]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float v[8];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) v[s] = ea[(32 * t) * LDT + 16 * m + s];
+          bf16x8 ah, am, al;
+          split3(v, ah, am, al);
+          gW2[t] = mfma_bf16x6(ah, am, al, bh[m], bm[m], bl[m], gW2[t]);
+        }
+      }
+    }
+#else
     {
       // gW2[k_in tile t][n = 32w + j] += sum_rows h1^T[k_in][row] * dz2^T[n][row]
       const float* ea = H1T + j * LDT + h;
@@ -791,6 +849,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#endif
     STAMP(5);
     __syncthreads();  // D: dz1^T complete
     {

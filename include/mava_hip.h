@@ -190,6 +190,9 @@ int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int R
 int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                      int x_share, int x_ld, const float* y, int K, int N, int rows, int want_bias,
                      float* slab, long slab_stride, int n_slab, mava_stream_t s);
+/* 0 (default): exact-f32 MFMAs; 1: X^T Y on six bf16 MFMAs per f32 product (operands split hi/mid/lo once while they are
+ * staged; f32 accuracy, parity-tested; currently slower - see rec_dense.hip).  For A/B measurements. */
+int mava_rec_xty_set_variant(int v);
 
 /* GRU over T steps (flax GRUCell; hidden state zeroed where done enters the step).  gi = W_i x + b_i
  * precomputed (T32, T*Rm x 384); wh (128 x 384) = [hr|hz|hn]; outputs hs (T32, h after each step) and,

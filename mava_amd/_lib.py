@@ -51,6 +51,7 @@ _SIGNATURES = {
     "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
                                            u32, vp, vp, vp, i32, vp],
     "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
+    "mava_rec_xty_set_variant": [i32],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,

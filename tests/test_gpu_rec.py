@@ -50,7 +50,8 @@ def test_rec_dense_t32(dev, K, N, relu, gated):
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want, 1e-5, "dense")
 
 
-def test_rec_dense_rowmajor_gather_and_xty(dev):
+@pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
+def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant):
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd import ops
 
@@ -144,8 +145,19 @@ def test_recurrent_forward_matches_oracle(dev, shared):
     assert_close(hs[-1], h_last, 1e-5, "final hidden state")
 
 
+@pytest.fixture
+def xty_variant(request):
+    """0: exact-f32 MFMAs (default); 1: the six-bf16-product form of mava_rec_xty_f32."""
+    from mava_amd._lib import lib
+
+    lib().mava_rec_xty_set_variant(request.param)
+    yield request.param
+    lib().mava_rec_xty_set_variant(0)
+
+
+@pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
 @pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13)])
-def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA):
+def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant):
     from mava_amd import ops
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd.networks import DiscreteActionHead, MLPTorso

@@ -47,7 +47,7 @@ class RecWorkspace:
         if training:
             self.hprev, self.saved = f(H), f(4 * H)
             self.dy, self.dpost, self.dh_out, self.dgi, self.dgh, self.dxpre = f(n_out_max), f(H), f(H), f(G3), f(G3), f(H)
-            self.loss_partials = torch.zeros((64, 2), device=device)
+            self.loss_partials = torch.zeros((1024, 2), device=device)  # one partial per loss-kernel block (4 blocks per CU)
 
 
 class _RecurrentNet:

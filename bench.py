@@ -52,6 +52,45 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: N child processes of this script with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set (what torch.distributed.run would export), rank 0's stdout (the JSON line) relayed.
+    Returns non-zero if any rank fails.  The parent never initialises the GPU."""
+    import subprocess
+
+    n_dev = torch.cuda.device_count()  # counts devices without initialising HIP on this image
+    if n_dev < n and os.environ.get("MAVA_DIST_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {n} but only {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
+              f"(MAVA_DIST_BACKEND=gloo rehearses several ranks on one card)", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def log(msg: str) -> None:
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -84,6 +123,11 @@ def main() -> None:
     args = ap.parse_args()
     continuous = args.action_head == "continuous"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Invoked without a launcher (`python bench.py --gpus N`): start the N ranks ourselves, one fresh child process
+        # per GPU, BEFORE anything in this process touches the GPU (no exec of a process that initialised HIP).
+        raise SystemExit(_spawn_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,8 +146,9 @@ def main() -> None:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        world = dist.get_world_size()  # n_gpus of the JSON line = the ranks the process group really has
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but the job has {world} rank(s)", file=sys.stderr)
 
     from mava_amd import envs
     from mava_amd.config import compose
@@ -117,7 +162,9 @@ def main() -> None:
         cfg.network.action_head = {"_target_": "mava.networks.ContinuousActionHead"}
         cfg.env.scenario.task_config.num_agents = args.agents
         cfg.env.synthetic = {"obs_dim": args.obs_dim, "num_actions": args.action_dim}
-    cfg.system.num_updates_per_eval = 1
+    # the timed call is learn(state) itself, num_updates_per_eval = steps updates per call, timed like
+    # run_experiment does (mava/systems/ppo/ff_mappo.py:496-504: wall time of learn + block_until_ready)
+    cfg.system.num_updates_per_eval = max(args.steps, 1)
     cfg.system.num_updates = max(args.steps + args.warmup, 1)
     central = args.system.endswith("mappo")
     mod = {"ff_mappo": ff_mappo, "ff_ippo": ff_ippo, "rec_mappo": rec_mappo, "rec_ippo": rec_ippo}[args.system]
@@ -143,23 +190,36 @@ def main() -> None:
         L.update(0)
         torch.cuda.synchronize()
         log(f"warmup update {i} done")
-    # ---- the timed region: exactly args.steps updates, no instrumentation inside
+    # ---- the timed region: ONE learn(state) call = exactly args.steps updates through the drop-in boundary
+    # (adopt + updates + the returned state's leaf stacking), no instrumentation inside
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        L.update(0)
+    out_state = learn(state)
     barrier()
     elapsed = time.perf_counter() - t0
+    assert tuple(out_state.train_metrics["total_loss"].shape[:2]) == (1, max(args.steps, 1))
+    assert bool(torch.isfinite(out_state.train_metrics["total_loss"]).all()), "non-finite loss in the timed updates"
     # ---- instrumented pass (NOT part of `value`): the same updates again with a HIP event pair around every
     # kernel launch on the launch stream, for the per-kernel roofline figures.  ~430 event pairs per update cost
     # ~1.5 ms, which is why they stay out of the timed region.
     timer_steps = 0
+    rec_timers = None
     if not args.no_kernel_timers and hasattr(L, "_timed"):
         L.timers = {}
         timer_steps = max(1, min(args.steps, 5))
         for _ in range(timer_steps):
             L.update(0)
         torch.cuda.synchronize()
+        barrier()
+    elif not args.no_kernel_timers:
+        from mava_amd import _lib as _mava_lib_mod
+
+        _mava_lib_mod.TIMERS = rec_timers = {}
+        timer_steps = max(1, min(args.steps, 2))
+        for _ in range(timer_steps):
+            L.update(0)
+        torch.cuda.synchronize()
+        _mava_lib_mod.TIMERS = None
         barrier()
     if world > 1:
         import torch.distributed as dist
@@ -196,14 +256,18 @@ def main() -> None:
                    "parallelism": f"dp{world}"},
     }
 
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/r01_v5_pmc_traffic.json): counters
-    # cannot be read from inside this process, so the measured figures of the same workload are attached.
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")) as f:
-            traffic = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM traffic per launch: counters cannot be read from inside this process, so `traffic` is NOT measured in this
+    # run - it is attached from the committed rocprofv3 PMC pass of the same workload named in `traffic_source`
+    # (regenerated per round with tools/pmc_traffic.sh; stale once a kernel changes after that pass).
+    traffic, traffic_source = {}, None
+    for name in ("r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["kernels"]
+            traffic_source = f"profiles/{name} (committed rocprofv3 --pmc pass, not measured in this run)"
+            break
+        except (OSError, ValueError, KeyError):
+            continue
     default_shape = (args.envs == 4096 and args.update_batch_size == 1 and args.scenario == "tiny-4ag"
                      and args.system == "ff_mappo" and not continuous)
 
@@ -228,10 +292,12 @@ def main() -> None:
                   "bound": "mfma", "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
                   "traffic": (traffic.get("ppo_train_kernel<critic>", {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "traffic_source": traffic_source if default_shape else None,
                   "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c, "rows_per_launch": rows_c}
         roof_a = {"kernel": "ppo_train_kernel<actor> (fused fwd+loss+bwd+dW)", "bound": "mfma", "achieved": tf_a,
                   "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_a / F32_MFMA_PEAK_TFLOPS,
                   "traffic": (traffic.get("ppo_train_kernel<actor>", {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "traffic_source": traffic_source if default_shape else None,
                   "avg_launch_ms": avg["actor_grad"], "flop_per_launch": flop_a, "rows_per_launch": rows}
         # "roofline" = the dominant kernel of the update (most time per update)
         if avg["actor_grad"] >= avg["critic_grad"]:
@@ -264,6 +330,56 @@ def main() -> None:
                                 "unit": "GB/s", "avg_launch_us": avg["clip_adam"] * 1e3}
         per_update = {k: sum(v) / timer_steps for k, v in timers.items()}
         out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in per_update.items()}
+
+    if rank == 0 and rec_timers:
+        # Recurrent systems: the kernel with the most time per update is the roofline object.  The GRU scans
+        # are priced on BOTH rooflines - algorithmic FLOPs (h.W_h: 2*128*384 per row-step, exact-f32 MFMA peak) and
+        # algorithmic HBM bytes per row-step (forward: read gi 1536 + done, write h 512 + saved gates 2048 + h_prev 512;
+        # BPTT: read saved 2048 + h_prev 512 + dh_out 512, write dgi 1536 + dgh 1536) - the binding one is `bound`.
+        timers = {k: _ev_ms(v) for k, v in rec_timers.items()}
+        per_update = {k: sum(v) / timer_steps for k, v in timers.items()}
+        avg = {k: sum(v) / len(v) for k, v in timers.items() if v}
+        out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in per_update.items()}
+        # launches are keyed "<kernel>:<sequences per step>" (actor: Rm = envs x agents of a minibatch; the centralised
+        # critic on a shared state: one sequence per env)
+        dom_key = max((k for k in per_update if k.startswith("gru_scan")), key=lambda k: per_update[k])
+        dom, seqs = dom_key.split(":")[0], int(dom_key.split(":")[1])
+        rows_avg = T * seqs                   # row-steps per launch
+        flop = 2.0 * 128 * 384 * rows_avg
+        by = {"gru_scan_fwd": 1536 + 1 + 512 + 2048 + 512, "gru_scan_bwd": 2048 + 512 + 512 + 1536 + 1536}[dom] * rows_avg
+        t_s = avg[dom_key] * 1e-3
+        tf, gbs = flop / t_s / 1e12, by / t_s / 1e9
+        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tf / F32_MFMA_PEAK_TFLOPS
+        rec_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_rec_v5_pmc.json")) as f:
+                rec_traffic = (json.load(f).get("kernels", {}).get(f"{dom}_kernel grid={min(256, seqs // 32)}", {})
+                               .get("hbm_bytes_corrected")) if (seqs == 8192 and T == 128) else None
+        except (OSError, ValueError, KeyError):
+            pass
+        if hbm_frac >= mfma_frac:
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": hbm_frac, "traffic": rec_traffic, "mfma_frac": mfma_frac}
+        else:
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": mfma_frac, "traffic": rec_traffic, "hbm_frac": hbm_frac}
+        out["roofline"].update({"avg_launch_ms": avg[dom_key], "row_steps_per_launch": rows_avg,
+                                "traffic_source": "profiles/r01_rec_v5_pmc.json (committed PMC pass)" if rec_traffic else None})
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("rec") and not continuous:
+        from oracle import rec_cpu_loop
+
+        cores = usable_cores()
+        cpu_E = max(2 * M, min(args.cpu_envs, 32))
+        log(f"cpu baseline (recurrent) on {cores} usable cores, {cpu_E} envs ...")
+        res = rec_cpu_loop.run(E=cpu_E, A=A, Oa=L.Oa, Oc=L.Oc, nA=L.nA, T=T, K=K, M=M, updates=8, warmup=0, threads=cores,
+                               max_seconds=args.cpu_seconds, shared_state=central)
+        out["cpu_baseline"] = {
+            "value": res["env_steps_per_sec"], "unit": "env-steps/s", "cores": res["threads"], "kind": "port",
+            "sample": f"oracle/rec_cpu_loop.py (torch-CPU f32 restatement of the same recurrent PPO update loop) at {cpu_E} envs x "
+                      f"{T} steps, {res['env_steps']} env-steps in {res['seconds']:.1f} s; substitute for Mava's JAX CPU path",
+        }
+        log(f"cpu baseline: {res['env_steps_per_sec']:,.0f} env-steps/s")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("ff") and not continuous:
         from oracle import cpu_loop

@@ -162,14 +162,17 @@ int mava_ppo_set_critic_aggregation(int on);
  * outputs: agents_view (E,A,A+O), global_state (E,gs_tiles,W) with gs_tiles in {1,A} and W = A*O (concatenated
  * raw views, RWARE) when state_dim == 0 or W = state_dim (independent state vector, SMAX-shaped),
  * action_mask (E,A,n_actions) u8, obs_step_count (E,A) i32; transition: reward (E,A) f32,
- * done (E,A) u8, info_return (E) f32, info_length (E) i32, info_terminal (E) u8. */
+ * done (E,A) u8, info_return (E) f32, info_length (E) i32, info_terminal (E) u8.
+ * reward_mode 0: team reward Bernoulli(0.02), independent of the actions (the measurement workload);
+ * reward_mode 1 ("match", for learning tests): team reward = fraction of the env's agents whose `action` (E,A) i32 -
+ * taken on the previous observation - equals (that observation's first grid coordinate) mod n_actions. */
 int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int state_dim, int time_limit,
                           uint64_t seed, uint32_t t, const uint32_t* t_base, uint32_t env_offset, int is_reset,
                           int32_t* step_count, float* run_return, int32_t* run_length,
                           float* ep_return, int32_t* ep_length, float* agents_view,
                           float* global_state, uint8_t* action_mask, int32_t* obs_step_count,
                           float* reward, uint8_t* done, float* info_return, int32_t* info_length,
-                          uint8_t* info_terminal, mava_stream_t s);
+                          uint8_t* info_terminal, const int32_t* action, int reward_mode, mava_stream_t s);
 
 /* ---- recurrent systems (rec_ippo / rec_mappo): mava/networks.py:238-331 (ScannedRNN GRU with
  *      reset-on-done, RecurrentActor, RecurrentValueNet), mava/systems/ppo/rec_mappo.py:91-149,

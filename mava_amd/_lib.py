@@ -57,7 +57,7 @@ _SIGNATURES = {
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
-    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 15,
+    "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 14 + [vp, i32, vp],
     "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
     "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
     "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -101,6 +101,24 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().mava_last_error().decode("utf-8", "replace")
         raise MavaHipError(f"{what} failed with code {rc}: {msg}")
+
+
+# bench.py: when set to a dict, every launch() call is bracketed by a HIP event pair on the current stream
+# (name -> [(start, end)]); None in production: launch() is then a plain call + check
+TIMERS: Optional[dict] = None
+
+
+def launch(what: str, fn, *args) -> None:
+    """check(fn(*args), what), optionally timed with HIP events on the launch stream."""
+    if TIMERS is None:
+        check(fn(*args), what)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    TIMERS.setdefault(what, []).append((a, b))
+    check(rc, what)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -15,6 +15,8 @@
 //   agents_view = [one-hot id (A) | 2 grid coordinates U{0..9} | O-2 Bernoulli(51/256) bits]
 //   action_mask = all legal except action 1 which is illegal w.p. 51/256
 //   reward      = 1.0 w.p. 0.02 (team), done = step_count reaches time_limit or w.p. 0.002
+//   reward_mode 1 ("match", opt-in, for learning tests): team reward = fraction of the env's agents whose action equals
+//   (first grid coordinate of the observation they acted on) mod n_actions - the only action-dependent quantity
 // Restated bit-for-bit in oracle/synth_env.py.
 #include "common.h"
 
@@ -49,6 +51,8 @@ struct SynthArgs {
   int32_t* info_length; // (E) or null
   uint8_t* info_terminal;  // (E) or null
   int is_reset;
+  const int32_t* action;   // (E, A) actions taken on the previous observation; read only when reward_mode == 1
+  int reward_mode;         // 0: Bernoulli(0.02) team reward; 1: "match" (see the header)
 };
 
 // One thread per 16-feature CHUNK of a raw view (= one Philox block: every draw is a pure function of
@@ -130,7 +134,16 @@ __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
   // ---- per-env draws (recomputed by every agent thread of the env: identical values)
   Philox4 ev = philox4x32_10(env_id, a.t, 0u, ENV_STREAM ^ 1u, a.seed_lo, a.seed_hi);
   const int sc_old = a.is_reset ? 0 : a.step_count[k];
-  const float rew = (!a.is_reset && u01_open(ev.x) < 0.02f) ? 1.0f : 0.0f;
+  float rew = (!a.is_reset && u01_open(ev.x) < 0.02f) ? 1.0f : 0.0f;
+  if (a.reward_mode == 1 && !a.is_reset) {
+    // the observation the agents acted on was generated at step t - 1: its first coordinate is recomputed, not re-read
+    int hits = 0;
+    for (uint32_t a2 = 0; a2 < A; ++a2) {
+      const Philox4 pc = philox4x32_10(env_id * A + a2, a.t - 1u, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
+      hits += (a.action[e * A + a2] == (int32_t)((pc.x % 10u) % (uint32_t)a.nA)) ? 1 : 0;
+    }
+    rew = (float)hits / (float)A;
+  }
   const int sc_new = sc_old + 1;
   const bool term = !a.is_reset && ((sc_new >= a.time_limit) || (u01_open(ev.y) < 0.002f));
   const int sc_obs = (a.is_reset || term) ? 0 : sc_new;
@@ -179,7 +192,8 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
                                      float* global_state, uint8_t* action_mask,
                                      int32_t* obs_step_count, float* reward, uint8_t* done,
                                      float* info_return, int32_t* info_length,
-                                     uint8_t* info_terminal, hipStream_t s) {
+                                     uint8_t* info_terminal, const int32_t* action, int reward_mode,
+                                     hipStream_t s) {
   MAVA_ARG_CHECK(E >= 0 && A >= 1 && O >= 2 && n_actions >= 1 && time_limit >= 1, 0,
                  "mava_synth_rware_step: bad shape E=%d A=%d O=%d nA=%d", E, A, O, n_actions);
   MAVA_ARG_CHECK((gs_tiles == 1 || gs_tiles == A) && state_dim >= 0, 1,
@@ -198,6 +212,9 @@ extern "C" int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_
   a.global_state = global_state; a.action_mask = action_mask; a.obs_step_count = obs_step_count;
   a.reward = reward; a.done = done; a.info_return = info_return; a.info_length = info_length;
   a.info_terminal = info_terminal; a.is_reset = is_reset;
+  MAVA_ARG_CHECK(reward_mode == 0 || (reward_mode == 1 && (is_reset || action != nullptr)), 5,
+                 "mava_synth_rware_step: reward_mode %d needs the (E, A) action array", reward_mode);
+  a.action = action; a.reward_mode = reward_mode;
   MAVA_ARG_CHECK(state_dim == 0 || state_dim >= 2, 1, "mava_synth_rware_step: state_dim must be 0 or >= 2");
   const long nch = (O - 2 + 15) / 16 > 0 ? (O - 2 + 15) / 16 : 1;
   const long nch_s = state_dim > 0 ? ((state_dim - 2 + 15) / 16 > 0 ? (state_dim - 2 + 15) / 16 : 1) : 0;

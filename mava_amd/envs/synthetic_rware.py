@@ -18,6 +18,9 @@ from .._lib import check, lib, ptr, stream_ptr
 from ..types import Observation, ObservationGlobalState, TimeStep
 
 
+EVAL_KEY_TAG = 0x4556414C4556414C  # "EVALEVAL": xor-ed into the Philox key of the evaluation environments
+
+
 class SynthState(NamedTuple):
     step_count: torch.Tensor  # (E, A) i32
     run_return: torch.Tensor  # (E,) f32   running_count_episode_return
@@ -40,7 +43,8 @@ class SyntheticRware:
 
     def __init__(self, num_envs: int, num_agents: int, obs_dim: int = 66, num_actions: int = 5, time_limit: int = 500,
                  add_global_state: bool = False, add_agent_id: bool = True, seed: int = 42, env_offset: int = 0,
-                 tile_global_state: bool = False, device: Optional[torch.device] = None, state_dim: int = 0):
+                 tile_global_state: bool = False, device: Optional[torch.device] = None, state_dim: int = 0,
+                 reward_mode: str = "random"):
         if not add_agent_id:
             raise NotImplementedError("the synthetic generator always prepends the agent one-hot id (add_agent_id=True)")
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
@@ -50,13 +54,19 @@ class SyntheticRware:
         self.gs_tiles = self.num_agents if tile_global_state else 1
         self.synth_state_dim = int(state_dim)  # 0: global_state = concatenated raw views; > 0: own state vector
         self.global_state_shared = not tile_global_state
+        # "random": Bernoulli(0.02) team reward, independent of the actions (the measurement workload of SURVEY 8d);
+        # "match": team reward = fraction of agents whose action equals (first grid coordinate they observed) mod
+        # n_actions - an action-dependent task, so that runs can show the PPO stack LEARNS (tests/test_gpu_learning.py)
+        if reward_mode not in ("random", "match"):
+            raise ValueError(f"reward_mode must be 'random' or 'match', got {reward_mode!r}")
+        self.reward_mode = reward_mode
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     def clone(self, env_offset: int, num_envs: Optional[int] = None) -> "SyntheticRware":
         """Same environment family on a disjoint range of global env ids (one per replica / rank)."""
         return SyntheticRware(num_envs or self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.time_limit,
                               self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device,
-                              self.synth_state_dim)
+                              self.synth_state_dim, self.reward_mode)
 
     # ---- specs ----------------------------------------------------------------------------
     @property
@@ -89,11 +99,15 @@ class SyntheticRware:
     # ---- kernel call ----------------------------------------------------------------------
     def step_into(self, state: SynthState, t: int, obs: Dict[str, torch.Tensor], reward=None, done=None, info_return=None,
                   info_length=None, info_terminal=None, is_reset: bool = False, env_offset: Optional[int] = None,
-                  t_base: Optional[torch.Tensor] = None) -> None:
+                  t_base: Optional[torch.Tensor] = None, action: Optional[torch.Tensor] = None) -> None:
         """One vectorised step (or reset) writing the next observation into `obs` and the transition
         into the given (E, A) / (E,) slots.  `t` is the replica's global step index (Philox counter); `t_base`
         (a device int32 word) is added to it on the device, for rollouts replayed from a captured graph."""
         off = self.env_offset if env_offset is None else env_offset
+        match = self.reward_mode == "match"
+        if match and not is_reset:
+            if action is None or action.dtype != torch.int32 or action.numel() != self.num_envs * self.num_agents:
+                raise ValueError("reward_mode='match' needs the (E, A) int32 actions of the step")
         check(
             lib().mava_synth_rware_step(self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.gs_tiles,
                                         self.synth_state_dim, self.time_limit, self.seed & 0xFFFFFFFFFFFFFFFF, t & 0xFFFFFFFF, ptr(t_base),
@@ -102,7 +116,7 @@ class SyntheticRware:
                                         ptr(state.ep_return), ptr(state.ep_length), ptr(obs["agents_view"]),
                                         ptr(obs["global_state"]), ptr(obs["action_mask"]), ptr(obs["step_count"]),
                                         ptr(reward), ptr(done), ptr(info_return), ptr(info_length), ptr(info_terminal),
-                                        stream_ptr()),
+                                        ptr(action) if match else None, int(match), stream_ptr()),
             "mava_synth_rware_step",
         )
 
@@ -135,7 +149,8 @@ class SyntheticRware:
         il = torch.empty(E, dtype=torch.int32, device=d)
         it = torch.empty(E, dtype=torch.uint8, device=d)
         t = int(state.t) + 1
-        self.step_into(state, t, obs, reward, done, ir, il, it)
+        self.step_into(state, t, obs, reward, done, ir, il, it,
+                       action=action.to(torch.int32).contiguous() if self.reward_mode == "match" else None)
         state = state._replace(t=torch.tensor(t, dtype=torch.int64))
         last = it.bool()
         extras = {"episode_metrics": {"episode_return": ir, "episode_length": il, "is_terminal_step": last}}
@@ -152,7 +167,10 @@ def make(config, add_global_state: bool = False, device=None, env_offset: int = 
     kw = dict(num_agents=int(tc.num_agents), obs_dim=int(syn["obs_dim"]), num_actions=int(syn["num_actions"]),
               time_limit=int(config.env.kwargs.get("time_limit", 500)), add_global_state=add_global_state,
               add_agent_id=bool(config.system.add_agent_id) and not bool(config.env.implicit_agent_id),
-              seed=int(config.system.seed), device=device, state_dim=int(syn.get("state_dim", 0) or 0))
-    train = SyntheticRware(num_envs=int(config.arch.num_envs), env_offset=env_offset, **kw)
-    evale = SyntheticRware(num_envs=int(config.arch.num_eval_episodes), env_offset=env_offset + (1 << 30), **kw)
+              device=device, state_dim=int(syn.get("state_dim", 0) or 0), reward_mode=str(syn.get("reward_mode", "random")))
+    seed = int(config.system.seed)
+    train = SyntheticRware(num_envs=int(config.arch.num_envs), env_offset=env_offset, seed=seed, **kw)
+    # The evaluation envs draw from their own Philox KEY (not an env-id offset: the kernel forms the per-agent counter
+    # (env_offset + e) * A + agent in 32 bits, where an offset of 2^30 wraps back onto the training envs for A >= 4).
+    evale = SyntheticRware(num_envs=int(config.arch.num_eval_episodes), env_offset=env_offset, seed=seed ^ EVAL_KEY_TAG, **kw)
     return train, evale

@@ -67,6 +67,11 @@ class _Replica:
         self.info_return = torch.zeros((n_upd, T, E), device=d)
         self.info_length = torch.zeros((n_upd, T, E), dtype=torch.int32, device=d)
         self.info_terminal = torch.zeros((n_upd, T, E), dtype=torch.uint8, device=d)
+        # the rollout writes the metrics of the CURRENT update here (fixed addresses: one captured HIP graph serves
+        # every update index n); FFLearner._rollout copies them to slot n afterwards
+        self.cur_return = torch.zeros((T, E), device=d)
+        self.cur_length = torch.zeros((T, E), dtype=torch.int32, device=d)
+        self.cur_terminal = torch.zeros((T, E), dtype=torch.uint8, device=d)
         self.last_reward = torch.zeros((E, A), device=d)
         self.last_done = torch.zeros((E, A), dtype=torch.uint8, device=d)
 
@@ -146,7 +151,7 @@ class FFLearner:
         # MAVA_GRAPH_ROLLOUT=0 turns it off, =force keeps it on with several ranks.
         mode = os.environ.get("MAVA_GRAPH_ROLLOUT", "1")
         self.graph_rollout = mode == "force" or (mode != "0" and self.world == 1)
-        self._graphs: Dict[Tuple[int, int], Any] = {}
+        self._graphs: Dict[int, Any] = {}  # keyed by the seed: ONE graph for every update index n
         self._graph_seen: set = set()
         self.seed = int(s.seed)
         self.timers: Optional[Dict[str, list]] = None  # bench.py: name -> [(start_event, end_event)]
@@ -239,31 +244,36 @@ class FFLearner:
     # ------------------------------------------------------------------------------------ update
     def _rollout(self, n: int) -> None:
         """The launch-bound part of an update (2*T + 3 small kernels per replica): rollout, bootstrap value and GAE.
-        The first call for an `n` runs eagerly, the second is captured into a HIP graph, later ones replay it -
-        the kernels read the moving step counter from step_dev, everything else they touch is persistent."""
+        The first call runs eagerly, the second is captured into a HIP graph, later ones replay it - the kernels
+        read the moving step counter from step_dev, everything else they touch (incl. the metrics staging slots)
+        is persistent, so the one graph serves every update index."""
         if not self.graph_rollout or self.timers is not None:
-            self._rollout_body(n)
+            self._rollout_body()
             self._bootstrap_and_gae()
         else:
-            key = (n, self.seed)
+            key = self.seed
             graph = self._graphs.get(key)
             if graph is None and key in self._graph_seen:
                 # thread_local: every launch of the rollout comes from this thread; RCCL's watchdog thread may query
                 # its events meanwhile
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    self._rollout_body(n)
+                    self._rollout_body()
                     self._bootstrap_and_gae()
                 self._graphs[key] = graph
             if graph is None:
                 self._graph_seen.add(key)
-                self._rollout_body(n)
+                self._rollout_body()
                 self._bootstrap_and_gae()
             else:
                 graph.replay()
+        for rep in self.reps:  # episode metrics of update n (ff_mappo.py:95,299); outside the graph: n moves
+            rep.info_return[n].copy_(rep.cur_return)
+            rep.info_length[n].copy_(rep.cur_length)
+            rep.info_terminal[n].copy_(rep.cur_terminal)
         self.t_global += self.T
 
-    def _rollout_body(self, n: int) -> None:
+    def _rollout_body(self) -> None:
         """ff_mappo.py:76-106: T acting steps, recording the time-major trajectory in place."""
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         EA = self.E * self.A
@@ -291,7 +301,8 @@ class FFLearner:
                                 out=(rep.action[t].view(EA), rep.log_prob[t].view(EA), rep.value[t].view(EA)), **common)
                 last = t == self.T - 1
                 self._timed("env_step", rep.env.step_into, rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t],
-                            rep.info_return[n, t], rep.info_length[n, t], rep.info_terminal[n, t], t_base=self.step_dev)
+                            rep.cur_return[t], rep.cur_length[t], rep.cur_terminal[t], t_base=self.step_dev,
+                            action=None if self.continuous else rep.action[t])
                 if last:
                     rep.last_reward.copy_(rep.reward[t])
                     rep.last_done.copy_(rep.done[t])

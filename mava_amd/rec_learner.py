@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from . import ops, parallel
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import check, launch, lib, ptr, stream_ptr
 from .learner import NUM_CU, _Replica
 from .networks import MLPTorso, make_action_head
 from .rec_networks import H, RecurrentActor, RecurrentValueNet, RecWorkspace, rows_to_t32, t32_to_rows
@@ -228,14 +228,14 @@ class RecLearner:
                             ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]), *critic_args),
                             "mava_rec_step_continuous_f32")
                     else:
-                        check(lib().mava_rec_step_f32(
-                            ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(rep.action_mask[t]), ptr(d_prev),
-                            ptr(rep.h_actor), ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]),
-                            *critic_args), "mava_rec_step_f32")
+                        launch("rec_step", lib().mava_rec_step_f32,
+                               ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(rep.action_mask[t]), ptr(d_prev),
+                               ptr(rep.h_actor), ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]),
+                               *critic_args)
                     rep.h_actor, rep.h_actor_next = rep.h_actor_next, rep.h_actor
                     rep.h_critic, rep.h_critic_next = rep.h_critic_next, rep.h_critic
                     rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
-                                      rep.info_length[n, t], rep.info_terminal[n, t])
+                                      rep.info_length[n, t], rep.info_terminal[n, t], action=None if self.continuous else rep.action[t])
                     continue
                 rep.done_in[t].copy_(rep.dones)
                 d1 = rep.done_in[t : t + 1]
@@ -267,7 +267,7 @@ class RecLearner:
                                                          y_out=rep.value[t])
                 rep.h_critic, ws.hs = ws.hs, rep.h_critic
                 rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
-                                  rep.info_length[n, t], rep.info_terminal[n, t])
+                                  rep.info_length[n, t], rep.info_terminal[n, t], action=None if self.continuous else rep.action[t])
                 rep.dones.copy_(rep.done[t])
                 if t == self.T - 1:
                     rep.last_reward.copy_(rep.reward[t])

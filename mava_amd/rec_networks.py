@@ -20,7 +20,7 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import check, launch, lib, ptr, stream_ptr
 from .distributions import Categorical
 from .networks import ContinuousActionHead, DiscreteActionHead, MLPTorso, _orthogonal_
 
@@ -172,20 +172,18 @@ class _RecurrentNet:
         while k0 < din:
             kc = min(384, din - k0)
             last = k0 + kc >= din
-            check(L.mava_rec_dense_f32(x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din, int(k0 > 0),
-                                       Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre),
-                                       kc, H, rows, int(last), s), "rec_dense(pre)")
+            launch("rec_dense(pre)", L.mava_rec_dense_f32, x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din, int(k0 > 0),
+                   Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows, int(last), s)
             k0 += kc
-        check(L.mava_rec_dense_f32(ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H, G3, rows, 0, s),
-              "rec_dense(gi)")
-        check(L.mava_gru_scan_fwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"), ptr(ws.gi),
-                                      ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s),
-              "gru_scan_fwd")
-        check(L.mava_rec_dense_f32(ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None, ptr(ws.post), H, H, rows,
-                                   1, s), "rec_dense(post)")
+        launch("rec_dense(gi)", L.mava_rec_dense_f32, ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H,
+               G3, rows, 0, s)
+        launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
+               ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
+        launch("rec_dense(post)", L.mava_rec_dense_f32, ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None,
+               ptr(ws.post), H, H, rows, 1, s)
         y = ws.y if y_out is None else y_out
-        check(L.mava_rec_dense_f32(ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"), None, ptr(y), H,
-                                   self.n_out, rows, 0, s), "rec_dense(head)")
+        launch("rec_dense(head)", L.mava_rec_dense_f32, ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"),
+               None, ptr(y), H, self.n_out, rows, 0, s)
         return y
 
     def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
@@ -199,19 +197,19 @@ class _RecurrentNet:
         WheadT = self.seg(flat, "Whead").t().contiguous()
         WpostT = self.seg(flat, "Wpost").t().contiguous()
         WiT = self.seg(flat, "Wi").t().contiguous()
-        d = lambda k, N, x, w, ldw, gate, y: check(
-            L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), k, N, rows, 0, s),
-            "rec_dense(bwd)")
+        d = lambda k, N, x, w, ldw, gate, y: launch(
+            "rec_dense(bwd)", L.mava_rec_dense_f32, ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), k, N,
+            rows, 0, s)
         d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
         d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
-        check(L.mava_gru_scan_bwd_f32(T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved), ptr(ws.hprev),
-                                      ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s), "gru_scan_bwd")
+        launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved),
+               ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
         d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
 
         def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
             """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
-            check(L.mava_rec_xty_f32(x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), K, N, rows, 1,
-                                     ptr(slabs), slabs.shape[1], slabs.shape[0], s), "rec_xty")
+            launch("rec_xty", L.mava_rec_xty_f32, x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), K, N,
+                   rows, 1, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
             ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
             if b_off is not None:
                 tail = slabs[:, K * N + bias_slice : K * N + bias_slice + nb].contiguous()

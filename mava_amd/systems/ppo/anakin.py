@@ -114,6 +114,10 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
     best_params = None
     t = 0
     for eval_step in range(int(config.arch.num_evaluation)):
+        # The reference evaluates `learner_state.params` of the state that went INTO learn() (ff_mappo.py:513-518; the
+        # state is only advanced at :535 - SURVEY Q3).  Here learn() updates the parameter buffers in place and the
+        # state's leaves are views of them, so the pre-update parameters are snapshotted first (outside the timed window).
+        trained_params = _tree_clone(learner_state.params.actor_params)
         torch.cuda.synchronize()
         start = time.time()
         out = learn(learner_state)
@@ -134,8 +138,7 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
             if ep_completed:
                 logger.log(ep_metrics, t, eval_step, LogEvent.ACT)
             logger.log(out.train_metrics, t, eval_step, LogEvent.TRAIN)
-        # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:516 vs :541)
-        trained_params = learner_state.params.actor_params
+        # evaluation uses the PRE-update parameters, exactly like the reference (ff_mappo.py:513-518 vs :535)
         eval_metrics = evaluator(trained_params, key_e + eval_step, init_act_state)
         if logger is not None:
             logger.log(eval_metrics, t, eval_step, LogEvent.EVAL)
@@ -143,8 +146,7 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
         rec["eval_episode_return"] = eval_return
         emit(rec)
         if bool(config.arch.absolute_metric) and max_episode_return <= eval_return:
-            # copy.deepcopy(trained_params), ff_mappo.py:537-539: the trees are views of buffers learn() updates in place
-            best_params = _tree_clone(trained_params)
+            best_params = trained_params  # copy.deepcopy(trained_params), ff_mappo.py:537-539: already a snapshot
             max_episode_return = eval_return
         learner_state = out.learner_state
         if checkpointer is not None:

@@ -23,7 +23,7 @@ from .synth_env import SynthRware
 class OracleLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, D=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95,
                  clip_eps=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4,
-                 decay=False, num_updates=1, time_limit=500, shared_gs=True, continuous=False):
+                 decay=False, num_updates=1, time_limit=500, shared_gs=True, continuous=False, reward_mode="random"):
         self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
         self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U, self.D = E, A, O, nA, T, K, M, U, D
@@ -32,7 +32,7 @@ class OracleLearner:
                       lrs=(actor_lr, critic_lr), decay=decay, num_updates=num_updates)
         self.Oa = A + O
         self.Oc = A * O if centralised else self.Oa
-        self.envs = [[SynthRware(E, A, O, nA, time_limit, seed, env_offset=(d * U + u) * E) for u in range(U)] for d in range(D)]
+        self.envs = [[SynthRware(E, A, O, nA, time_limit, seed, env_offset=(d * U + u) * E, reward_mode=reward_mode) for u in range(U)] for d in range(D)]
         self.obs = [[e.reset(0) for e in row] for row in self.envs]
         self.t_global = 0
         self.counts = [0, 0]
@@ -72,7 +72,7 @@ class OracleLearner:
                 action = po.gumbel_argmax(z, uni).reshape(E, A)
                 lp = po.log_softmax(z)[np.arange(E * A), action.reshape(-1)]
             value = po.mlp_forward(pc, cx.reshape(E * A, -1))[:, 0]
-            obs, reward, done, info = env.step(step + 1)
+            obs, reward, done, info = env.step(step + 1, action=None if self.continuous else action)
             for k, v in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", value.reshape(E, A)),
                          ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done", done),
                          ("ret", info["episode_return"]), ("len", info["episode_length"]), ("term", info["is_terminal_step"])):

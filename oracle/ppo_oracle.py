@@ -158,25 +158,33 @@ def normalise_advantages(gae_mb):
     return (gae_mb - gae_mb.mean()) / (gae_mb.std() + 1e-8)
 
 
-def actor_loss_and_grad(flat, din, no, obs, mask, action, old_log_prob, gae_mb, clip_eps, ent_coef):
+def actor_loss_and_grad(flat, din, no, obs, mask, action, old_log_prob, gae_mb, clip_eps, ent_coef, part_of=None):
     """Returns (total_loss, actor_loss, entropy, flat_grad).  Shapes: obs (R, din), mask (R, no),
-    action/old_log_prob/gae_mb (R,) with R = minibatch rows * agents, flattened."""
+    action/old_log_prob/gae_mb (R,) with R = minibatch rows * agents, flattened.
+    part_of = (R_total, adv_mean, adv_std): the rows are one CHUNK of a minibatch of R_total rows whose advantage
+    statistics are given; the returned losses and gradient are this chunk's share of the minibatch means (summing
+    the chunks gives the whole minibatch - how the full-launch-shape tests evaluate 10^6 rows in bounded memory)."""
     p = mlp_unflatten(flat, din, no)
     obs = np.asarray(obs, flat.dtype)
-    R = obs.shape[0]
+    n_rows = obs.shape[0]
     y, cache = mlp_forward(p, obs, keep=True)
     z = masked_logits(y, mask)
     logp_all = log_softmax(z)
     probs = np.exp(logp_all)
-    lp = logp_all[np.arange(R), action]
+    lp = logp_all[np.arange(n_rows), action]
     ratio = np.exp(lp - old_log_prob)
-    adv = normalise_advantages(np.asarray(gae_mb, flat.dtype))
+    if part_of is None:
+        R = n_rows
+        adv = normalise_advantages(np.asarray(gae_mb, flat.dtype))
+    else:
+        R, a_mean, a_std = part_of
+        adv = (np.asarray(gae_mb, flat.dtype) - a_mean) / (a_std + 1e-8)
     l1 = ratio * adv
     rc = np.clip(ratio, 1.0 - clip_eps, 1.0 + clip_eps)
     l2 = rc * adv
-    loss_actor = -np.minimum(l1, l2).mean()
+    loss_actor = -np.minimum(l1, l2).sum() / R
     ent_rows = categorical_entropy(logp_all)
-    entropy = ent_rows.mean()
+    entropy = ent_rows.sum() / R
     total = loss_actor - ent_coef * entropy
 
     # d(-min(l1,l2))/d ratio with even tie split (lax.min) and clip's pass-through inside the range
@@ -186,7 +194,7 @@ def actor_loss_and_grad(flat, din, no, obs, mask, action, old_log_prob, gae_mb, 
     dratio = -(g1 * adv + g2 * adv * inside) / R
     dlp = dratio * ratio
     onehot = np.zeros_like(y)
-    onehot[np.arange(R), action] = 1.0
+    onehot[np.arange(n_rows), action] = 1.0
     dz = dlp[:, None] * (onehot - probs)
     # entropy: dH/dz_o = -p_o (log p_o + H); total has -ent_coef * mean(H)
     dH = -probs * (np.where(probs > 0, logp_all, 0.0) + ent_rows[:, None])
@@ -197,18 +205,19 @@ def actor_loss_and_grad(flat, din, no, obs, mask, action, old_log_prob, gae_mb, 
     return total, loss_actor, entropy, mlp_flatten(grads)
 
 
-def critic_loss_and_grad(flat, din, x, old_value, targets, clip_eps, vf_coef):
-    """Returns (critic_total_loss, value_loss, flat_grad); x (R, din), old_value/targets (R,)."""
+def critic_loss_and_grad(flat, din, x, old_value, targets, clip_eps, vf_coef, R_total=None):
+    """Returns (critic_total_loss, value_loss, flat_grad); x (R, din), old_value/targets (R,).
+    R_total: the rows are one chunk of a minibatch of R_total rows (see actor_loss_and_grad.part_of)."""
     p = mlp_unflatten(flat, din, 1)
     x = np.asarray(x, flat.dtype)
-    R = x.shape[0]
+    R = x.shape[0] if R_total is None else R_total
     y, cache = mlp_forward(p, x, keep=True)
     v = y[:, 0]
     diff = v - old_value
     vclip = old_value + np.clip(diff, -clip_eps, clip_eps)
     l1 = (v - targets) ** 2
     l2 = (vclip - targets) ** 2
-    value_loss = 0.5 * np.maximum(l1, l2).mean()
+    value_loss = 0.5 * np.maximum(l1, l2).sum() / R
     total = vf_coef * value_loss
     inside = (diff >= -clip_eps) & (diff <= clip_eps)
     g1 = np.where(l1 > l2, 1.0, np.where(l1 == l2, 0.5, 0.0))

@@ -22,7 +22,7 @@ from .synth_env import SynthRware
 class OracleRecLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95, clip_eps=0.2,
                  ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4, time_limit=500, state_dim=0,
-                 continuous=False):
+                 continuous=False, reward_mode="random"):
         self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
         self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U = E, A, O, nA, T, K, M, U
@@ -30,7 +30,8 @@ class OracleRecLearner:
         self.h = dict(gamma=gamma, lam=gae_lambda, clip=clip_eps, ent=ent_coef, vf=vf_coef, mgn=max_grad_norm, lrs=(actor_lr, critic_lr))
         self.Oa = A + O
         self.Oc = (state_dim if state_dim > 0 else A * O) if centralised else self.Oa
-        self.envs = [SynthRware(E, A, O, nA, time_limit, seed, env_offset=u * E, state_dim=state_dim) for u in range(U)]
+        self.envs = [SynthRware(E, A, O, nA, time_limit, seed, env_offset=u * E, state_dim=state_dim, reward_mode=reward_mode)
+                     for u in range(U)]
         self.obs = [e.reset(0) for e in self.envs]
         self.dones = [np.zeros((E, A), bool) for _ in range(U)]
         self.ha = [np.zeros((E * A, 128)) for _ in range(U)]
@@ -70,7 +71,7 @@ class OracleRecLearner:
                 lp = po.log_softmax(z)[np.arange(E * A), action]
                 action = action.reshape(E, A)
             v, _, self.hc[u] = ro.rec_forward(self.pc, self.Oc, 1, cx.reshape(1, E * A, -1), d_in[None], self.hc[u])
-            obs, reward, done, info = env.step(step + 1)
+            obs, reward, done, info = env.step(step + 1, action=None if self.continuous else action)
             for k, val in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", v[0, :, 0].reshape(E, A)),
                            ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done_in", self.dones[u].copy()),
                            ("ret", info["episode_return"]), ("len", info["episode_length"]), ("term", info["is_terminal_step"])):

@@ -19,10 +19,11 @@ from .philox import ENV_STREAM, philox4x32_10, u01_open
 
 class SynthRware:
     def __init__(self, E: int, A: int, O: int = 66, n_actions: int = 5, time_limit: int = 500, seed: int = 42,
-                 env_offset: int = 0, gs_tiles: int = 1, state_dim: int = 0):
+                 env_offset: int = 0, gs_tiles: int = 1, state_dim: int = 0, reward_mode: str = "random"):
         self.E, self.A, self.O, self.nA = E, A, O, n_actions
         self.time_limit, self.seed, self.env_offset, self.gs_tiles = time_limit, seed, env_offset, gs_tiles
         self.state_dim = state_dim
+        self.reward_mode = reward_mode  # "random" | "match" (action-dependent team reward, see synth_rware.hip)
         self.step_count = np.zeros((E, A), np.int32)
         self.run_return = np.zeros(E, np.float32)
         self.run_length = np.zeros(E, np.int32)
@@ -79,13 +80,21 @@ class SynthRware:
         obs["step_count"] = self.step_count.copy()
         return obs
 
-    def step(self, t: int):
-        """Returns (obs, reward (E,A), done (E,A), info) - actions do not influence the stream."""
+    def step(self, t: int, action=None):
+        """Returns (obs, reward (E,A), done (E,A), info).  reward_mode "random": actions do not influence the stream;
+        "match": team reward = fraction of agents whose action equals (first coordinate of the observation generated at
+        step t - 1, the one they acted on) mod n_actions."""
         E, A = self.E, self.A
         slo, shi = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
         env_id = (np.arange(E, dtype=np.uint64) + np.uint64(self.env_offset)).astype(np.uint32)
         ev = philox4x32_10(env_id, t, 0, ENV_STREAM ^ 1, slo, shi)
         rew = (u01_open(ev[0]) < np.float32(0.02)).astype(np.float32)
+        if self.reward_mode == "match":
+            ent = (env_id[:, None].astype(np.uint64) * np.uint64(A) + np.arange(A, dtype=np.uint64)[None, :]).astype(np.uint32)
+            pc = philox4x32_10(ent, t - 1, 0xFFFF, ENV_STREAM, slo, shi)
+            target = ((pc[0] % np.uint32(10)) % np.uint32(self.nA)).astype(np.int64)
+            hits = (np.asarray(action).reshape(E, A).astype(np.int64) == target).sum(1)
+            rew = hits.astype(np.float32) / np.float32(A)
         sc_new = self.step_count[:, 0] + 1
         term = (sc_new >= self.time_limit) | (u01_open(ev[1]) < np.float32(0.002))
         obs = self._observe(t)

@@ -330,6 +330,73 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
     assert_close(got[P:P + 1], np.array([vl]), 1e-5, "value loss", scale=1.0)
 
 
+def test_train_kernels_full_launch_shape(dev):
+    """BASELINE config 2's REAL launch shape: one minibatch of Rb = 262 144 (t,e) indices out of T*E = 524 288,
+    A = 4 -> 1 048 576 agent rows, 256 slabs (one persistent block per CU), 32-bit row cursors over the 2 M-row
+    trajectory - against the float64 oracle evaluated in chunks (oracle/ppo_oracle.py part_of / R_total)."""
+    from mava_amd import ops
+
+    TE, A, O, nA, Rb, n_slab = 524288, 4, 66, 5, 262144, 256
+    rng = np.random.default_rng(2024)
+    rows, din, dc = TE * A, O + A, A * O
+    av = rng.standard_normal((rows, din), dtype=np.float32)
+    gs = rng.standard_normal((TE, dc), dtype=np.float32)
+    mask = rng.random((rows, nA), dtype=np.float32) > 0.25
+    action = rng.integers(0, nA, rows).astype(np.int32)
+    mask[np.arange(rows), action] = True
+    adv = (rng.standard_normal(rows, dtype=np.float32) * 2.0 + 0.3).astype(np.float32)
+    fa = _net(rng, din, nA, 1.0).astype(np.float32)
+    fc = _net(rng, dc, 1, 1.0).astype(np.float32)
+    idx = rng.permutation(TE)[:Rb].astype(np.int32)
+    sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)  # agent rows of the minibatch, kernel order
+    R = sel.size
+    pa = po.mlp_unflatten(fa.astype(np.float64), din, nA)
+    pc = po.mlp_unflatten(fc.astype(np.float64), dc, 1)
+    old_lp = np.zeros(rows, np.float32)
+    old_v = np.zeros(rows, np.float32)
+    tgt = np.zeros(rows, np.float32)
+    CH = 1 << 16
+    for lo in range(0, R, CH):  # old log-probs / values near the current ones: both sides of the clip ranges
+        r = sel[lo : lo + CH]
+        lsm = po.log_softmax(po.masked_logits(po.mlp_forward(pa, av[r].astype(np.float64)), mask[r]))
+        old_lp[r] = (lsm[np.arange(r.size), action[r]] + rng.standard_normal(r.size) * 0.25).astype(np.float32)
+        v = po.mlp_forward(pc, gs[r // A].astype(np.float64))[:, 0]
+        old_v[r] = (v + rng.standard_normal(r.size) * 0.2).astype(np.float32)
+        tgt[r] = (v + rng.standard_normal(r.size)).astype(np.float32)
+
+    idx_d, adv_d = _t(idx, dev), _t(adv, dev)
+    Pa, Pc = fa.size, fc.size
+    slab_a = torch.zeros((n_slab, Pa + 2), device=dev)
+    slab_c = torch.zeros((n_slab, Pc + 2), device=dev)
+    stats = ops.adv_stats(adv_d, idx_d, 0, Rb, A)
+    ops.ppo_actor_grad(_t(fa, dev), _t(av, dev), _t(mask, dev), _t(action, dev), _t(old_lp, dev), adv_d, stats, idx_d, 0,
+                       Rb, A, nA, 0.2, 0.01, slab_a)
+    ops.ppo_critic_grad(_t(fc, dev), _t(gs, dev), A, _t(old_v, dev), _t(tgt, dev), idx_d, 0, Rb, A, 0.2, 0.5, slab_c)
+    out_a = torch.zeros(Pa + 2, device=dev)
+    out_c = torch.zeros(Pc + 2, device=dev)
+    ops.slab_reduce(slab_a, Pa + 2, out_a)
+    ops.slab_reduce(slab_c, Pc + 2, out_c)
+    torch.cuda.synchronize()
+
+    a64 = adv[sel].astype(np.float64)
+    part = (R, a64.mean(), a64.std())
+    acc_a = [0.0, 0.0, 0.0, np.zeros(Pa)]
+    acc_c = [0.0, 0.0, np.zeros(Pc)]
+    for lo in range(0, R, CH):
+        r = sel[lo : lo + CH]
+        o = po.actor_loss_and_grad(fa.astype(np.float64), din, nA, av[r].astype(np.float64), mask[r], action[r],
+                                   old_lp[r].astype(np.float64), adv[r].astype(np.float64), 0.2, 0.01, part_of=part)
+        acc_a = [x + y for x, y in zip(acc_a, o)]
+        o = po.critic_loss_and_grad(fc.astype(np.float64), dc, gs[r // A].astype(np.float64), old_v[r].astype(np.float64),
+                                    tgt[r].astype(np.float64), 0.2, 0.5, R_total=R)
+        acc_c = [x + y for x, y in zip(acc_c, o)]
+    ga, gc = out_a.cpu().numpy(), out_c.cpu().numpy()
+    assert_close(ga[:Pa], acc_a[3], 1e-4, "actor grad, full launch shape")  # north_star: PPO gradients 1e-4
+    assert_close(ga[Pa:], np.array([acc_a[1], acc_a[2]]), 1e-5, "actor loss/entropy", scale=1.0)
+    assert_close(gc[:Pc], acc_c[2], 1e-4, "critic grad, full launch shape")
+    assert_close(gc[Pc : Pc + 1], np.array([acc_c[1]]), 1e-5, "value loss", scale=1.0)
+
+
 @pytest.mark.parametrize("variant", [1, 11, 21, 22, 23, 24, 41, 42, 43, 44, 45, 46, 47])
 @pytest.mark.parametrize("T,N,rec", [(128, 16384, False), (37, 136, True), (300, 264, False)])
 def test_gae_variants(dev, variant, T, N, rec):

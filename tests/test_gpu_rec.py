@@ -119,13 +119,15 @@ def _gather(x, idx, A, shared):
     return g.reshape(g.shape[0], g.shape[1] * g.shape[2], *g.shape[3:])
 
 
-@pytest.mark.parametrize("shared", [False, True])
-def test_recurrent_forward_matches_oracle(dev, shared):
+# the last case is BASELINE config 4's shape at full sequence length: rec_mappo SMAX 3s5z, 8 agents, actor input
+# 155, 13 actions, seq_len = 128 (f32 error growth over 128 GRU steps against the float64 oracle)
+@pytest.mark.parametrize("shared,T,E,A,Em,din,nA", [(False, 9, 12, 4, 8, 37, 6), (True, 9, 12, 4, 8, 37, 6),
+                                                    (False, 128, 8, 8, 4, 155, 13), (True, 128, 8, 8, 4, 188, 1)])
+def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA):
     from mava_amd.networks import DiscreteActionHead, MLPTorso
     from mava_amd.rec_networks import RecurrentActor, RecWorkspace, t32_to_rows
 
     rng = np.random.default_rng(11)
-    T, E, A, Em, din, nA = 9, 12, 4, 8, 37, 6
     obs, done, h0, idx = _seq_case(rng, T, E, A, Em, din, nA, shared)
     net = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
     flat = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
@@ -143,6 +145,7 @@ def test_recurrent_forward_matches_oracle(dev, shared):
     assert_close(got, want, 1e-5, "recurrent logits")
     hs = t32_to_rows(ws.hs, 128, T * Rm).cpu().numpy().reshape(T, Rm, 128)
     assert_close(hs[-1], h_last, 1e-5, "final hidden state")
+    assert_close(hs[:-1], hs_in[1:], 1e-5, "hidden states of every step")
 
 
 @pytest.fixture
@@ -156,7 +159,9 @@ def xty_variant(request):
 
 
 @pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
-@pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13)])
+# (128, 8, 8, 4, 155, 13): BPTT over the FULL sequence length of BASELINE config 4 (seq_len = 128, 8 agents, input 155,
+# 13 actions) - actor and critic gradients at the north-star 1e-4 against float64 autograd
+@pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13), (128, 8, 8, 4, 155, 13)])
 def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant):
     from mava_amd import ops
     from mava_amd._lib import check, lib, ptr, stream_ptr

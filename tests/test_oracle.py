@@ -317,3 +317,137 @@ def test_continuous_head_numpy_vs_torch_autograd():
     _, dmean, dscale = tn.log_prob_terms(a, mean, tn.scale_of(ls))
     np.testing.assert_allclose(m_t.grad.numpy(), w[:, None] * dmean, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(ls_t.grad.numpy(), (w[:, None] * dscale).sum(0) * tn.sigmoid(ls), rtol=1e-7, atol=1e-10)
+
+
+# ------------------------------------------------------------------ third-party restatements pinned to torch
+# The reference's arithmetic that lives in flax / optax / tfp cannot be executed here (oracle headers).  What IS
+# importable is torch, whose GRUCell, Adam and Categorical are independent implementations of the same published
+# algebra - they pin the oracle's restatements of those three (not Mava itself: "parity unpinned" stands).
+def test_gru_step_matches_torch_grucell():
+    """flax.linen.GRUCell (networks.py:258) restated in oracle/rec_oracle.py:gru_step == torch.nn.GRUCell with
+    b_hr = b_hz = 0 (flax's hr / hz sub-modules carry no bias), weights transposed to torch's (3H, in) layout."""
+    import torch
+
+    from oracle import rec_oracle as ro
+
+    rng = np.random.default_rng(3)
+    H = ro.H
+    p = {"Wi": rng.standard_normal((H, 3 * H)) / np.sqrt(H), "bi": rng.standard_normal(3 * H) * 0.1,
+         "Wh": rng.standard_normal((H, 3 * H)) / np.sqrt(H), "bhn": rng.standard_normal(H) * 0.1}
+    x, h = rng.standard_normal((37, H)), rng.standard_normal((37, H))
+    cell = torch.nn.GRUCell(H, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(p["Wi"].T.copy()))
+        cell.weight_hh.copy_(torch.from_numpy(p["Wh"].T.copy()))
+        cell.bias_ih.copy_(torch.from_numpy(p["bi"]))
+        cell.bias_hh.copy_(torch.from_numpy(np.concatenate([np.zeros(2 * H), p["bhn"]])))
+        want = cell(torch.from_numpy(x), torch.from_numpy(h)).numpy()
+    assert np.allclose(ro.gru_step(p, x, h), want, rtol=1e-12, atol=1e-13)
+    # several steps with resets, through the torch (autograd) restatement the BPTT gradients come from
+    flat = ro.init_rec(rng, 11, 5, 1.0)
+    flat[11 * H + H + H * 3 * H:][: 3 * H] = rng.standard_normal(3 * H) * 0.1  # bi
+    xs, dn, h0 = rng.standard_normal((6, 9, 11)), rng.random((6, 9)) < 0.3, rng.standard_normal((9, H))
+    q = ro.rec_unflatten(flat, 11, 5)
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(q["Wi"].T.copy()))
+        cell.weight_hh.copy_(torch.from_numpy(q["Wh"].T.copy()))
+        cell.bias_ih.copy_(torch.from_numpy(q["bi"]))
+        cell.bias_hh.copy_(torch.from_numpy(np.concatenate([np.zeros(2 * H), q["bhn"]])))
+        hh = torch.from_numpy(h0)
+        for t in range(6):
+            hh = torch.where(torch.from_numpy(dn[t])[:, None], torch.zeros_like(hh), hh)
+            hh = cell(torch.relu(torch.from_numpy(xs[t]) @ torch.from_numpy(q["Wpre"]) + torch.from_numpy(q["bpre"])), hh)
+    _, _, h_last = ro.rec_forward(flat, 11, 5, xs, dn, h0)
+    assert np.allclose(h_last, hh.numpy(), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_clip_adam_matches_torch_optim(big):
+    """optax.chain(clip_by_global_norm(0.5), adam(lr, eps=1e-5)) restated in po.clip_adam == torch.optim.Adam
+    (betas (.9, .999), eps 1e-5: eps added outside the square root, like optax with eps_root = 0) fed with the
+    gradient clipped by torch.nn.utils.clip_grad_norm_ (which divides by norm + 1e-6: agreement to 4e-6)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n = 300
+    p0 = rng.standard_normal(n)
+    w = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([w], lr=2.5e-4, betas=(0.9, 0.999), eps=1e-5)
+    p, m, v, c = p0.copy(), np.zeros(n), np.zeros(n), 0
+    for step in range(25):
+        g = rng.standard_normal(n) * (1.0 if big else 0.01)  # big: norm >> 0.5, the clip is active
+        w.grad = torch.from_numpy(g.copy())
+        torch.nn.utils.clip_grad_norm_([w], 0.5)
+        opt.step()
+        p, m, v, c = po.clip_adam(p, g, m, v, c, 2.5e-4, 0.5)
+        assert np.allclose(p - p0, w.detach().numpy() - p0, rtol=1e-5, atol=1e-12), step
+    st = opt.state[w]
+    assert np.allclose(m, st["exp_avg"].numpy(), rtol=1e-5, atol=1e-15)
+    assert np.allclose(v, st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-18) and c == 25
+
+
+def test_masked_categorical_matches_torch_distributions():
+    """tfd.Categorical(logits=where(mask, logits, finfo(f32).min)) (networks.py:116-124) restated in po ==
+    torch.distributions.Categorical on the same masked logits: log_prob, entropy, mode."""
+    import torch
+
+    rng = np.random.default_rng(7)
+    y = rng.standard_normal((64, 7)) * 3
+    mask = rng.random((64, 7)) > 0.4
+    mask[:, 2] = True
+    z = po.masked_logits(y, mask)
+    d = torch.distributions.Categorical(logits=torch.from_numpy(z))
+    a = rng.integers(0, 7, 64)
+    a = np.where(mask[np.arange(64), a], a, 2)
+    lsm = po.log_softmax(z)
+    assert np.allclose(lsm[np.arange(64), a], d.log_prob(torch.from_numpy(a)).numpy(), rtol=1e-12, atol=1e-12)
+    assert np.allclose(po.categorical_entropy(lsm), d.entropy().numpy(), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(z.argmax(-1), d.probs.argmax(-1).numpy())
+    assert (np.exp(lsm)[~mask] == 0).all()
+
+
+def test_chunked_loss_evaluation_equals_whole_minibatch():
+    """part_of / R_total: summing chunk shares reproduces the whole-minibatch loss and gradient (used by the
+    full-launch-shape GPU tests)."""
+    rng = np.random.default_rng(11)
+    R, din, nA = 300, 13, 5
+    flat = po.mlp_flatten(po.init_mlp(rng, din, nA, 1.0))
+    obs, mask = rng.standard_normal((R, din)), rng.random((R, nA)) > 0.2
+    act = rng.integers(0, nA, R)
+    mask[np.arange(R), act] = True
+    olp, adv = -np.abs(rng.standard_normal(R)), rng.standard_normal(R) * 2 + 0.3
+    tot, la, ent, g = po.actor_loss_and_grad(flat, din, nA, obs, mask, act, olp, adv, 0.2, 0.01)
+    acc = np.zeros(4, object)
+    acc = [0.0, 0.0, 0.0, np.zeros_like(g)]
+    for lo in range(0, R, 77):
+        sl = slice(lo, lo + 77)
+        out = po.actor_loss_and_grad(flat, din, nA, obs[sl], mask[sl], act[sl], olp[sl], adv[sl], 0.2, 0.01,
+                                     part_of=(R, adv.mean(), adv.std()))
+        acc = [a + b for a, b in zip(acc, out)]
+    assert np.allclose([tot, la, ent], acc[:3], rtol=1e-12) and np.allclose(g, acc[3], rtol=1e-10, atol=1e-15)
+    fc = po.mlp_flatten(po.init_mlp(rng, din, 1, 1.0))
+    ov, tg = rng.standard_normal(R), rng.standard_normal(R)
+    tot, vl, g = po.critic_loss_and_grad(fc, din, obs, ov, tg, 0.2, 0.5)
+    acc = [0.0, 0.0, np.zeros_like(g)]
+    for lo in range(0, R, 64):
+        sl = slice(lo, lo + 64)
+        acc = [a + b for a, b in zip(acc, po.critic_loss_and_grad(fc, din, obs[sl], ov[sl], tg[sl], 0.2, 0.5, R_total=R))]
+    assert np.allclose([tot, vl], acc[:2], rtol=1e-12) and np.allclose(g, acc[2], rtol=1e-10, atol=1e-15)
+
+
+def test_oracle_learns_match_task():
+    """The oracle's whole-update loop LEARNS the synthetic env's action-dependent "match" task (team reward = fraction
+    of agents whose action equals the first grid coordinate they observed, mod n_actions): the signs of the restated
+    loss / gradient / Adam chain are right end to end.  The GPU counterpart is tests/test_gpu_learning.py."""
+    from oracle.ppo_loop import OracleLearner
+
+    E, A, O, nA, T, K, M = 32, 2, 10, 5, 16, 4, 2
+    rng = np.random.default_rng(0)
+    ora = OracleLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=1, centralised=True, seed=42, actor_lr=3e-3, critic_lr=3e-3,
+                        gamma=0.5, reward_mode="match", time_limit=50)
+    ora.set_params(po.mlp_flatten(po.init_mlp(rng, A + O, nA, 0.01)), po.mlp_flatten(po.init_mlp(rng, A * O, 1, 1.0)))
+    rs = []
+    for _ in range(60):
+        ora.update([rng.permutation(T * E).astype(np.int32) for _ in range(K)])
+        rs.append(ora.last_traj[0][0]["reward"].mean())
+    assert np.mean(rs[:3]) < 0.35 and np.mean(rs[-5:]) > 0.55, (rs[:3], rs[-5:])

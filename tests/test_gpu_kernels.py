@@ -333,10 +333,17 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
 def test_train_kernels_full_launch_shape(dev):
     """BASELINE config 2's REAL launch shape: one minibatch of Rb = 262 144 (t,e) indices out of T*E = 524 288,
     A = 4 -> 1 048 576 agent rows, 256 slabs (one persistent block per CU), 32-bit row cursors over the 2 M-row
-    trajectory - against the float64 oracle evaluated in chunks (oracle/ppo_oracle.py part_of / R_total)."""
+    trajectory - against the float64 oracle evaluated in chunks (oracle/ppo_oracle.py part_of / R_total).
+
+    Rows with a hidden pre-activation within 5e-5 of a ReLU kink are kept OUT of the minibatch: the derivative is
+    discontinuous there, so float32 (this kernel, or the reference's own f32 XLA program) and float64 legitimately
+    take different branches, and at this size ONE such row moves 128 gradient entries by ~1.5e-4 of the gradient's
+    rms (measured: 3 of 26 245 entries off by 1.1e-7 with the kink rows in) - a property of the test, not of the
+    arithmetic.  ~4 % of the (t,e) indices are dropped this way."""
     from mava_amd import ops
 
     TE, A, O, nA, Rb, n_slab = 524288, 4, 66, 5, 262144, 256
+    KINK = 5e-5
     rng = np.random.default_rng(2024)
     rows, din, dc = TE * A, O + A, A * O
     av = rng.standard_normal((rows, din), dtype=np.float32)
@@ -347,22 +354,36 @@ def test_train_kernels_full_launch_shape(dev):
     adv = (rng.standard_normal(rows, dtype=np.float32) * 2.0 + 0.3).astype(np.float32)
     fa = _net(rng, din, nA, 1.0).astype(np.float32)
     fc = _net(rng, dc, 1, 1.0).astype(np.float32)
-    idx = rng.permutation(TE)[:Rb].astype(np.int32)
-    sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)  # agent rows of the minibatch, kernel order
-    R = sel.size
     pa = po.mlp_unflatten(fa.astype(np.float64), din, nA)
     pc = po.mlp_unflatten(fc.astype(np.float64), dc, 1)
     old_lp = np.zeros(rows, np.float32)
     old_v = np.zeros(rows, np.float32)
     tgt = np.zeros(rows, np.float32)
-    CH = 1 << 16
-    for lo in range(0, R, CH):  # old log-probs / values near the current ones: both sides of the clip ranges
-        r = sel[lo : lo + CH]
-        lsm = po.log_softmax(po.masked_logits(po.mlp_forward(pa, av[r].astype(np.float64)), mask[r]))
+    cand = rng.permutation(TE)
+    keep = []
+    CH = 1 << 14  # (t,e) indices per chunk = 65 536 agent rows
+    n_keep = 0
+    for lo in range(0, TE, CH):
+        ii = cand[lo : lo + CH]
+        r = (ii[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
+        y, (_, z1, _, z2, _) = po.mlp_forward(pa, av[r].astype(np.float64), keep=True)
+        vv, (_, c1, _, c2, _) = po.mlp_forward(pc, gs[ii].astype(np.float64), keep=True)
+        near = (np.minimum(np.abs(z1).min(1), np.abs(z2).min(1)) < KINK).reshape(-1, A).any(1)
+        near |= np.minimum(np.abs(c1).min(1), np.abs(c2).min(1)) < KINK
+        # old log-probs / values near the current ones: both sides of the clip ranges
+        lsm = po.log_softmax(po.masked_logits(y, mask[r]))
         old_lp[r] = (lsm[np.arange(r.size), action[r]] + rng.standard_normal(r.size) * 0.25).astype(np.float32)
-        v = po.mlp_forward(pc, gs[r // A].astype(np.float64))[:, 0]
+        v = np.repeat(vv[:, 0], A)
         old_v[r] = (v + rng.standard_normal(r.size) * 0.2).astype(np.float32)
         tgt[r] = (v + rng.standard_normal(r.size)).astype(np.float32)
+        keep.append(ii[~near])
+        n_keep += int((~near).sum())
+        if n_keep >= Rb:
+            break
+    idx = np.concatenate(keep)[:Rb].astype(np.int32)
+    assert idx.size == Rb
+    sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)  # agent rows of the minibatch, kernel order
+    R = sel.size
 
     idx_d, adv_d = _t(idx, dev), _t(adv, dev)
     Pa, Pc = fa.size, fc.size
@@ -382,8 +403,8 @@ def test_train_kernels_full_launch_shape(dev):
     part = (R, a64.mean(), a64.std())
     acc_a = [0.0, 0.0, 0.0, np.zeros(Pa)]
     acc_c = [0.0, 0.0, np.zeros(Pc)]
-    for lo in range(0, R, CH):
-        r = sel[lo : lo + CH]
+    for lo in range(0, R, 1 << 16):
+        r = sel[lo : lo + (1 << 16)]
         o = po.actor_loss_and_grad(fa.astype(np.float64), din, nA, av[r].astype(np.float64), mask[r], action[r],
                                    old_lp[r].astype(np.float64), adv[r].astype(np.float64), 0.2, 0.01, part_of=part)
         acc_a = [x + y for x, y in zip(acc_a, o)]

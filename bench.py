@@ -117,6 +117,9 @@ def main() -> None:
     ap.add_argument("--action-head", default="discrete", choices=["discrete", "continuous"],
                     help="continuous: network.action_head=ContinuousActionHead on a MaBrax-shaped synthetic env "
                          "(--agents, --obs-dim, --action-dim; SURVEY 8f N4) - a secondary workload, not the headline metric")
+    ap.add_argument("--matmul", default="f32", choices=["f32", "f16x2"],
+                    help="arithmetic of the fused PPO gradient kernels: exact-f32 MFMA, or split-f16 operands (3 f16 MFMAs per "
+                         "product, f32 accumulate; mava_ppo_set_matmul_mode)")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--obs-dim", type=int, default=27)
     ap.add_argument("--action-dim", type=int, default=2)
@@ -185,7 +188,10 @@ def main() -> None:
         from mava_amd._lib import lib as _mava_lib
 
         _mava_lib().mava_ppo_set_critic_aggregation(0)
-    log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc}")
+    from mava_amd._lib import lib as _mava_lib2
+
+    _mava_lib2().mava_ppo_set_matmul_mode(1 if args.matmul == "f16x2" else 0)
+    log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc} matmul={args.matmul}")
     for i in range(args.warmup):
         L.update(0)
         torch.cuda.synchronize()
@@ -246,7 +252,7 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.matmul == "f32" else "f32 via 2 x f16 split operands on the MFMA (3 products, f32 accumulate)",
         "data": "synthetic",
         "config": {"workload": (f"{args.system} ContinuousActionHead, MaBrax-shaped synthetic obs, " if continuous else
                                 f"{args.system} {args.env.upper()} {args.scenario}-shaped synthetic obs, ") + f"{E * U} envs/GPU "

@@ -154,6 +154,13 @@ int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_i
  * of its agents' loss gradients - mathematically the same gradient.  0 restores one pass per agent row. */
 int mava_ppo_set_critic_aggregation(int on);
 
+/* Arithmetic of mava_ppo_actor_grad_f32 / mava_ppo_critic_grad_f32 (process-wide).  0 (default): exact-f32 MFMA.
+ * 1: "f16x2" - every matrix operand split into two f16 terms (hi + lo, ~22 mantissa bits), three f16 MFMAs per product
+ * with f32 accumulation: 5.3x less matrix-pipe time, same 1e-4 gradient parity against the float64 oracle; applies to
+ * the shapes mava_amd/csrc/ppo_train_h2.hip instantiates, other shapes keep running the exact-f32 kernel. */
+int mava_ppo_set_matmul_mode(int mode);
+int mava_ppo_get_matmul_mode(void);
+
 /* ---- synthetic RWARE-shaped environment (measurement stand-in for the third-party Jumanji
  *      RobotWarehouse stepped at mava/systems/ppo/ff_mappo.py:88).  Wrapper semantics follow
  *      mava/wrappers/observation.py:41-53, jumanji.py:53-59,128-143, auto_reset_wrapper.py:88-101

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "mava_gae_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
     "mava_gae_set_variant": [i32],
     "mava_ppo_set_critic_aggregation": [i32],
+    "mava_ppo_set_matmul_mode": [i32],
+    "mava_ppo_get_matmul_mode": [],
     "mava_policy_set_variant": [i32],
     "mava_clip_adam": [vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, f32, f32, i32, i32, i32,
                        f32, f32, f32, vp, f32, f32, vp, vp],

@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "mlp_policy.hip",
     "mlp_coop.hip",
     "ppo_train.hip",
+    "ppo_train_h2.hip",
     "synth_rware.hip",
     "rec_dense.hip",
     "rec_gru.hip",

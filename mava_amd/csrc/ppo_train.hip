@@ -28,6 +28,7 @@
 // writes ONE partial-gradient slab; mava_slab_reduce_f32 sums slabs in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).
 #include "mlp_core.h"
+#include "ppo_train_task.h"
 #include "tanh_normal.h"
 
 namespace {
@@ -35,30 +36,6 @@ namespace {
 constexpr int STATS_BLOCKS = 128;
 constexpr int LDT = 33;  // row stride of the [feature][32 rows] exchange tiles
 
-struct TrainTask {
-  const float* params;
-  const float* x;          // (rows_x, din)
-  int din, no, xshare, xv;
-  int A;                   // agent rows per (t,e) index
-  int agg;                 // critic only: 1, or A when the A agents of an index share one input row and are
-                           // aggregated into it (one network pass per (t,e) row instead of A identical ones)
-  const int32_t* idx;      // minibatch (t*E+e) indices, or null => idx_base + b
-  long idx_base;
-  int Rb;                  // (t,e) rows in the minibatch; agent rows R = Rb * A
-  const uint8_t* mask;     // (TE*A, no) or null
-  const int32_t* action;   // (TE*A)
-  const float* action_f;   // continuous head: (TE*A, no) actions in (-1, 1); the raw scales follow the MLP in params
-  uint32_t seed_lo, seed_hi, ent_step, row_offset;  // continuous head: Philox key / counters of the entropy sample
-  const float* old_logp;   // (TE*A)
-  const float* adv;        // (TE*A)
-  const double* stats;     // STATS_BLOCKS x {sum, sumsq} partials of the minibatch advantages
-  const float* old_value;  // (TE*A)
-  const float* targets;    // (TE*A)
-  float clip_eps, ent_coef, vf_coef;
-  float* slab;
-  long slab_stride;
-  unsigned long long* stamps;  // diagnostic builds only (-DMAVA_STAMPS): per-phase cycle sums of block 0
-};
 
 #ifdef MAVA_STAMPS
 #define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1038,6 +1015,17 @@ extern "C" int mava_ppo_set_critic_aggregation(int on) {
   return MAVA_OK;
 }
 
+static int g_matmul_mode = 0;
+// Arithmetic of the fused PPO gradient kernels.  0: exact-f32 MFMA (v_mfma_f32_32x32x2_f32, ppo_train.hip);
+// 1: split-f16 operands, three v_mfma_f32_32x32x16_f16 per product, f32 accumulation (ppo_train_h2.hip) - used for the
+// shapes that kernel instantiates (discrete actor / critic, input width <= 95), everything else stays on mode 0.
+extern "C" int mava_ppo_set_matmul_mode(int mode) {
+  MAVA_ARG_CHECK(mode == 0 || mode == 1, 0, "mava_ppo_set_matmul_mode: mode %d (0 = exact f32, 1 = f16x2)", mode);
+  g_matmul_mode = mode;
+  return MAVA_OK;
+}
+extern "C" int mava_ppo_get_matmul_mode(void) { return g_matmul_mode; }
+
 extern "C" int mava_adv_stats_blocks(void) { return STATS_BLOCKS; }
 
 extern "C" int mava_adv_stats_f64(const float* adv, const int32_t* idx, long idx_base, int Rb, int A,
@@ -1072,6 +1060,10 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
   tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
   tk.slab_stride = slab_stride;
   tk.stamps = g_stamps;
+  if (g_matmul_mode == 1) {
+    const int rc = mava_train_h2_launch(tk, n_slab, true, s);
+    if (rc <= 0) return rc;  // launched (0) or failed (< 0); 1: shape not instantiated there
+  }
   if (n_actions <= 8) return dispatch_kt<8, true>(tk, n_slab, s);
   if (n_actions <= 16) return dispatch_kt<16, true>(tk, n_slab, s);
   return dispatch_kt<32, true>(tk, n_slab, s);
@@ -1130,5 +1122,9 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
   tk.old_value = old_value; tk.targets = targets; tk.clip_eps = clip_eps; tk.vf_coef = vf_coef;
   tk.slab = slab; tk.slab_stride = slab_stride;
   tk.stamps = g_stamps;
+  if (g_matmul_mode == 1) {
+    const int rc = mava_train_h2_launch(tk, n_slab, false, s);
+    if (rc <= 0) return rc;
+  }
   return dispatch_kt<1, false>(tk, n_slab, s);
 }

@@ -1,0 +1,769 @@
+// Fused PPO minibatch kernels on the f16 matrix pipe with SPLIT operands (the "f16x2" form of ppo_train.hip).
+//
+// Reference: mava/systems/ppo/ff_mappo.py:150-180 (_actor_loss_fn), :182-201 (_critic_loss_fn), :204-218
+// (value_and_grad), :268-285 (shuffle as an index vector) - the same math as ppo_train.hip, phase by phase.
+//
+// Arithmetic.  Every matrix operand x (f32) is split into two f16 terms, hi = f16(x), lo = f16(x - hi) (round to
+// nearest: x = hi + lo to ~2^-22 |x|), and a product a.b is evaluated as a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on
+// v_mfma_f32_32x32x16_f16 with f32 accumulation (the dropped a_lo.b_lo term is 2^-22 relative): three 32-cycle
+// MFMAs per 16 inputs instead of eight 64-cycle exact-f32 MFMAs - 5.3x less matrix-pipe time at ~22 mantissa bits
+// per operand.  The backward pass runs in units of R x gradient (R = rows of the minibatch: the 1/R of the losses'
+// .mean() is applied once when the slab is written), so loss gradients are O(1) - far from f16's subnormal range -
+// and the tiny W3 of a freshly initialised actor head (orthogonal(0.01)) is scaled by 2^7 inside the kernel.
+// Operands must stay below f16's 65504 (observations / activations / weights of these networks are orders of
+// magnitude smaller); the gradient parity tests (1e-4 against the float64 oracle) run on this kernel too.
+//
+// MI355X mapping.  Persistent 256-thread blocks, one per CU, 32-row tiles, wave w owns feature slice [32w, 32w+32) of
+// every layer; products are transposed (feature on the accumulator register, batch row on the lane) like ppo_train.hip.
+// What changed with the 16-bit MFMA (A[m][8 consecutive k], B[8 consecutive k][n] per lane):
+//   * the WEIGHTS never touch LDS: each lane keeps its pre-split fragments of W1 / W2 (column slice for layer 2, row
+//     slice for the backward product) / W3 in registers for the whole launch (8 registers per 16-input step);
+//   * activations cross waves through ONE LDS image per tensor, [32 rows][128 features] f16 in a hi and a lo plane
+//     (row stride 272 B = an odd number of 16-byte slots: conflict-free ds_read_b128 row reads), written once by the
+//     producer (which splits) and read two ways: ds_read_b128 along a row where the product sums over FEATURES
+//     (layer 2, dh1, dz2), ds_read_b64_tr_b16 (hardware transpose) where it sums over BATCH ROWS (the weight
+//     gradients h1^T.dz2, x^T.dz1, dy^T.h2) - no second layout, no consumer-side splitting;
+//   * the head's partial logits take the layer-2 accumulator straight as their B operand (accumulator registers
+//     8s..8s+7 of a lane ARE the k-step-s fragment of the next product, in a permuted k order the W3 fragment follows);
+//   * the x tile is double-buffered in LDS, which removes two of the seven barriers per tile.
+#include "mlp_core.h"
+#include "ppo_train_task.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned char u8;
+
+constexpr int STATS_BLOCKS = 128;  // == ppo_train.hip (mava_adv_stats_blocks)
+constexpr int IMG_ROW = 272;       // bytes per image row: 128 f16 + 16 (an odd number of 16-byte slots)
+constexpr int IMG_PLANE = 32 * IMG_ROW;
+constexpr int IMG_BYTES = 2 * IMG_PLANE;  // hi plane, lo plane
+constexpr int DY_ROW = 80;         // [32 rows][32 outputs] f16 + 16
+constexpr int DY_PLANE = 32 * DY_ROW;
+constexpr float W3_SCALE = 128.0f, W3_UNSCALE = 1.0f / 128.0f;
+
+struct Frag {  // one split MFMA operand: 8 k-values per lane as hi + lo
+  half8 hi, lo;
+};
+
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+  Frag f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 a, b;
+    split1(v[i], a, b);
+    f.hi[i] = a;
+    f.lo[i] = b;
+  }
+  return f;
+}
+__device__ __forceinline__ f32x16 mfma3(const Frag& a, const Frag& b, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);  // small terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+}
+
+// B-operand fragment where the product sums over the image's COLUMN (feature) index: 8 consecutive features of row r
+__device__ __forceinline__ Frag read_row_frag(const u8* img, int plane_bytes, int byte_off) {
+  Frag f;
+  f.hi = *reinterpret_cast<const half8*>(img + byte_off);
+  f.lo = *reinterpret_cast<const half8*>(img + plane_bytes + byte_off);
+  return f;
+}
+// Operand fragment where the product sums over the image's ROW (batch row) index: lane (r, h) receives column
+// (C0 + r) of rows R0 + 8h + 0..7 - two hardware-transposed reads per plane.  `a0` is this lane's byte address of
+// block row q = (lane & 15) >> 2, columns 4 * (lane & 3) .. + 3 of the FIRST 4-row block; the second block is 4 rows on.
+#define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
+__device__ __forceinline__ half8 read_tr8(const u8* a0, int row_bytes) {
+  const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a0));
+  const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(a0 + 4 * row_bytes));
+  return __builtin_bit_cast(half8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ Frag read_tr_frag(const u8* a0, int plane_bytes, int row_bytes) {
+  Frag f;
+  f.hi = read_tr8(a0, row_bytes);
+  f.lo = read_tr8(a0 + plane_bytes, row_bytes);
+  return f;
+}
+
+// accumulator tile (feature fo(q,h) of the wave's slice on register q, row r on the lane) -> split -> image rows.
+// Registers 4g..4g+3 of a lane are 4 consecutive features: one 8-byte store per plane and group.  The packed groups
+// are returned: groups (2s, 2s+1) of a lane are also the k-step-s fragment of a product that sums over these features.
+__device__ __forceinline__ void write_image(u8* img, int r, int col0 /* 32w + 4h */, const f32x16& acc, half4 (&ph)[4],
+                                            half4 (&pl)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a, b;
+      split1(acc[4 * g + e], a, b);
+      ph[g][e] = a;
+      pl[g][e] = b;
+    }
+    u8* p = img + r * IMG_ROW + 2 * (col0 + 8 * g);
+    *reinterpret_cast<half4*>(p) = ph[g];
+    *reinterpret_cast<half4*>(p + IMG_PLANE) = pl[g];
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int G, typename Op>
+__device__ __forceinline__ float group_allreduce(float v, Op op) {
+  v = op(v, dpp_f<0xB1>(v));
+  v = op(v, dpp_f<0x4E>(v));
+  if (G >= 8) v = op(v, dpp_f<0x141>(v));
+  if (G >= 16) v = op(v, dpp_f<0x140>(v));
+  if (G >= 32) v = op(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+
+struct H2Layout {  // byte offsets into the dynamic LDS array (all multiples of 16)
+  int h1, dz2, dz1, h2, xs, xs_plane, xs_row, dy, yp, agg, small, end;
+};
+
+template <int NO, int S1>
+H2Layout make_h2_layout(bool actor) {
+  constexpr int KT1 = (S1 + 1) / 2;
+  H2Layout L;
+  L.h1 = 0;
+  L.dz2 = L.h1 + IMG_BYTES;
+  L.dz1 = L.dz2 + IMG_BYTES;
+  L.h2 = L.dz1 + IMG_BYTES;  // actor only (B operand of dy^T.h2)
+  L.xs = L.h2 + (actor ? IMG_BYTES : 0);
+  L.xs_row = 2 * 32 * KT1 + 16;  // [32 rows][32*KT1 inputs] f16 + 16: an odd number of 16-byte slots
+  L.xs_plane = 32 * L.xs_row;
+  L.dy = L.xs + 2 * 2 * L.xs_plane;  // two buffers x (hi, lo)
+  L.yp = L.dy + 2 * DY_PLANE;
+  L.agg = L.yp + 4 * 32 * (NO + 1) * 4;
+  L.agg = (L.agg + 15) & ~15;
+  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[NO] | misc[16]
+  L.small = (L.small + 15) & ~15;
+  L.end = L.small + (128 + 32 + 16) * 4;
+  return L;
+}
+
+template <int NO, int S1, bool ACTOR>
+__global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2Layout L) {
+  constexpr int KT1 = (S1 + 1) / 2;  // 32-input tiles of the layer-1 weight gradient
+  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+  u8* const H1I = lds + L.h1;
+  u8* const DZ2I = lds + L.dz2;
+  u8* const DZ1I = lds + L.dz1;
+  u8* const H2I = lds + L.h2;
+  u8* const DYI = lds + L.dy;
+  float* const YP = reinterpret_cast<float*>(lds + L.yp);
+  float* const AGG = reinterpret_cast<float*>(lds + L.agg);
+  float* const B2s = reinterpret_cast<float*>(lds + L.small);
+  float* const B3s = B2s + 128;
+  float* const misc = B3s + 32;
+  const int xs_row = L.xs_row, xs_plane = L.xs_plane;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, h = lane >> 5, r = lane & 31;
+  const int srow = tid >> 3, l8 = tid & 7;  // staging role: row srow of the tile, 8 threads per row
+  const int din = tk.din, no = tk.no;
+  const long R = (!ACTOR && tk.agg > 1) ? (long)tk.Rb : (long)tk.Rb * tk.A;
+  const float invR = 1.0f / (float)((long)tk.Rb * tk.A);
+  constexpr int NR = (32 * KT1 + 7) / 8;  // staged floats per thread (scalar pieces, 8 threads per row)
+
+  // ---------------------------------------------------------------- prologue: LDS images, small vectors
+  for (int i = tid * 16; i < L.end; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  {
+    const float* p = tk.params;
+    if (tid < 128) B2s[tid] = p[mlp_off_b2(din) + tid];
+    if (tid < no) B3s[tid] = p[mlp_off_b3(din, no) + tid];
+    // the ones column of both x buffers: "row din" of W1 in the flat parameter vector is b1
+    if (tid < 64) {
+      const int b = tid >> 5, row = tid & 31;
+      *reinterpret_cast<_Float16*>(lds + L.xs + b * 2 * xs_plane + row * xs_row + 2 * din) = (_Float16)1.0f;
+    }
+    if (ACTOR && tid == 0) {
+      // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < STATS_BLOCKS; ++i) { s1 += tk.stats[2 * i]; s2 += tk.stats[2 * i + 1]; }
+      const double mean = s1 / (double)R;
+      double var = s2 / (double)R - mean * mean;
+      if (var < 0.0) var = 0.0;
+      misc[0] = (float)mean;
+      misc[1] = 1.0f / ((float)sqrt(var) + 1e-8f);
+    }
+  }
+  // ---------------------------------------------------------------- weight fragments, split once, register-resident
+  const float* const P = tk.params;
+  const int oW2 = mlp_off_w2(din), oW3 = mlp_off_w3(din);
+  Frag W1f[S1];  // A of layer 1: W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din is zero
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * h + e;
+      v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+    }
+    W1f[s] = split8(v);
+  }
+  Frag W2a[8];  // A of layer 2: W2[k = 16s + 8h + e][f = 32w + r]
+  Frag W2b[8];  // A of dh1 = W2 . dz2: W2[k = 32w + r][n = 16s + 8h + e]
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = P[oW2 + (16 * s + 8 * h + e) * MLP_H + 32 * w + r];
+    W2a[s] = split8(v);
+    const float4 b0 = *reinterpret_cast<const float4*>(P + oW2 + (32 * w + r) * MLP_H + 16 * s + 8 * h);
+    const float4 b1 = *reinterpret_cast<const float4*>(P + oW2 + (32 * w + r) * MLP_H + 16 * s + 8 * h + 4);
+    const float u[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    W2b[s] = split8(u);
+  }
+  // head: logits^T[o = r][row] += sum over the wave's 32 features, B = the layer-2 accumulator itself: element e of
+  // lane half h in k-step s is feature 32w + 16s + 8(e>>2) + 4h + (e&3)
+  Frag W3h[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = 32 * w + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+      v[e] = (r < no) ? P[oW3 + f * no + r] * W3_SCALE : 0.0f;
+    }
+    W3h[s] = split8(v);
+  }
+  Frag W3d;  // actor: A of dz2 = W3 . dy: W3[f = 32w + r][o = 8h + e]
+  float w3v[ACTOR ? 1 : 16];  // critic: W3[f] of the lane's 16 accumulator features (dz2 = W3[f] * dy on the VALU)
+  if (ACTOR) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = 8 * h + e;
+      v[e] = (o < no) ? P[oW3 + (32 * w + r) * no + o] * W3_SCALE : 0.0f;
+    }
+    W3d = split8(v);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w3v[q] = P[oW3 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
+  }
+  __syncthreads();
+  const float adv_mean = ACTOR ? misc[0] : 0.0f;
+  const float adv_rstd = ACTOR ? misc[1] : 0.0f;
+
+  // persistent accumulators (R x gradient units): wave w owns output columns [32w, 32w+32) of dW1 and dW2
+  f32x16 gW1[KT1], gW2[4], gW3;
+#pragma unroll
+  for (int t = 0; t < KT1; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gW1[t][q] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gW2[t][q] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) gW3[q] = 0.0f;
+  float ab2[16], aW3r[ACTOR ? 1 : 16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ab2[q] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < (ACTOR ? 1 : 16); ++q) aW3r[q] = 0.0f;
+  float ab3 = 0.0f, loss_a = 0.0f, loss_b = 0.0f;
+
+  // ---------------------------------------------------------------- row cursors and prefetch (as ppo_train.hip)
+  constexpr int NP = ACTOR ? NO / 8 : 1;
+  constexpr int GR = ACTOR ? 64 / NO : 32;
+  const int lo = ACTOR ? (lane & (NO - 1)) : 0;
+  auto loss_row = [&](int q) -> int { return ACTOR ? (8 * w + q * GR + lane / NO) : r; };
+  const int slot = 2 * w + h;
+  const int slot_c = (!ACTOR && tk.agg > 1) ? (slot < tk.agg ? slot : 0) : 0;
+  auto load_row = [&](long fr, int& act, float& f0, float& f1, uint32_t& m) {
+    if (ACTOR) {
+      act = tk.action[fr];
+      f0 = tk.old_logp[fr];
+      f1 = tk.adv[fr];
+      const uint8_t* mk = (tk.mask != nullptr && lo < no) ? (tk.mask + fr * no + lo) : nullptr;
+      m = 1u;
+      if (mk != nullptr) m = *mk;
+    } else {
+      act = 0;
+      const long fa = (tk.agg > 1) ? fr * tk.agg + slot_c : fr;
+      f0 = tk.old_value[fa];
+      f1 = tk.targets[fa];
+      m = 0u;
+    }
+  };
+  const uint32_t Au = (!ACTOR && tk.agg > 1) ? 1u : (uint32_t)tk.A;
+  const uint32_t q_step = 32u * gridDim.x, b_step = q_step / Au, a_step = q_step % Au;
+  const uint32_t b_last = (uint32_t)(R - 1) / Au, a_last = (uint32_t)(R - 1) % Au;
+  struct Cursor { uint32_t q, b, a; };
+  auto cursor_at = [&](int rr) {
+    Cursor c;
+    c.q = 32u * blockIdx.x + (uint32_t)rr;
+    c.b = c.q / Au;
+    c.a = c.q - c.b * Au;
+    return c;
+  };
+  auto cursor_advance = [&](Cursor& c) {
+    c.q += q_step; c.b += b_step; c.a += a_step;
+    if (c.a >= Au) { c.a -= Au; c.b += 1u; }
+  };
+  auto cursor_gather = [&](const Cursor& c, int32_t& p_raw, uint32_t& a_out) {
+    const bool in = c.q < (uint32_t)R;
+    const uint32_t b = in ? c.b : b_last;
+    a_out = in ? c.a : a_last;
+    p_raw = tk.idx ? tk.idx[b] : (int32_t)(tk.idx_base + (long)b);
+  };
+  auto stage_row = [&](int32_t p_raw, uint32_t a) -> uint32_t {
+    const uint32_t fr = (uint32_t)p_raw * Au + a;
+    return (tk.xshare == 1) ? fr : ((uint32_t)tk.xshare == Au ? (uint32_t)p_raw : fr / (uint32_t)tk.xshare);
+  };
+  // x staging: thread l8 of a row takes the scalar pieces l8, l8 + 8, ...; a piece past the row end is loaded from the
+  // row start and stored to a dummy slot (branch-free, see ppo_train.hip stage_load / stage_write)
+  auto stage_issue = [&](uint32_t xrow_idx, float (&xr)[NR]) {
+    const float* xrow = tk.x + (long)xrow_idx * din;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int c = l8 + 8 * i;
+      xr[i] = xrow[(c < din) ? c : 0];
+    }
+  };
+  _Float16* const xs_dummy = reinterpret_cast<_Float16*>(misc + 8);
+  auto stage_commit = [&](int buf, const float (&xr)[NR]) {
+    u8* base = lds + L.xs + buf * 2 * xs_plane + srow * xs_row;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int c = l8 + 8 * i;
+      _Float16 a, b;
+      split1(xr[i], a, b);
+      const bool ok = c < din;
+      *(ok ? reinterpret_cast<_Float16*>(base + 2 * c) : xs_dummy) = a;
+      *(ok ? reinterpret_cast<_Float16*>(base + xs_plane + 2 * c) : xs_dummy) = b;
+    }
+  };
+
+  const long ntiles = (R + 31) / 32;
+  long it = blockIdx.x;
+  float xr[NR];
+  int r_act[NP] = {}, n_act[NP] = {};
+  float r_f0[NP] = {}, r_f1[NP] = {}, n_f0[NP] = {}, n_f1[NP] = {};
+  uint32_t r_m[NP] = {}, n_m[NP] = {};
+  Cursor cs = cursor_at(srow), cl[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) cl[q] = cursor_at(loss_row(q));
+  int32_t ps_next = 0, pl_next[NP] = {};
+  uint32_t as_next = 0, al_next[NP] = {};
+  if (it < ntiles) {
+    cursor_gather(cs, ps_next, as_next);
+    stage_issue(stage_row(ps_next, as_next), xr);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      cursor_gather(cl[q], pl_next[q], al_next[q]);
+      load_row((long)((uint32_t)pl_next[q] * Au + al_next[q]), r_act[q], r_f0[q], r_f1[q], r_m[q]);
+    }
+    stage_commit(0, xr);
+    cursor_advance(cs);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+    if (it + gridDim.x < ntiles) {
+      cursor_gather(cs, ps_next, as_next);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+      cursor_advance(cs);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+    }
+  }
+  __syncthreads();
+
+  // per-lane LDS byte offsets
+  const int rowB = r * IMG_ROW + 16 * h;                       // + 32 s: features 16s + 8h .. + 7 of image row r
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, g1 = (lane >> 4) & 1;
+  // transposed reads: block row (8h + tq) of a 16-row step, columns (16 g1 + 4 tp) .. + 3 of a 32-column tile
+  const int trI = (8 * h + tq) * IMG_ROW + 2 * (16 * g1 + 4 * tp);  // + 16 s * IMG_ROW + 2 * (first column of the tile)
+  const int trX = (8 * h + tq) * xs_row + 2 * (16 * g1 + 4 * tp);
+  const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
+  int buf = 0;
+
+  for (; it < ntiles; it += gridDim.x, buf ^= 1) {
+    const bool valid = (it * 32 + r) < R;
+    const long itn = it + gridDim.x;
+    const bool have_next = itn < ntiles;
+    uint32_t xrow_next = stage_row(ps_next, as_next);
+    uint32_t fr_next[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) fr_next[q] = (uint32_t)pl_next[q] * Au + al_next[q];
+    asm volatile("" : "+v"(xrow_next));
+#pragma unroll
+    for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(fr_next[q]));
+    const u8* const XSI = lds + L.xs + buf * 2 * xs_plane;
+
+    // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const Frag b = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * s);
+      acc = mfma3(W1f[s], b, acc);
+    }
+    uint32_t relu1 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[q] = fmaxf(acc[q], 0.0f);
+      relu1 |= (acc[q] > 0.0f) ? (1u << q) : 0u;
+    }
+    {
+      half4 ph[4], pl[4];
+      write_image(H1I, r, 32 * w + 4 * h, acc, ph, pl);
+    }
+    // next tile's gathers: issued after P1 (their latency hides under P2..P4), committed to the OTHER x buffer
+    if (have_next) {
+      stage_issue(xrow_next, xr);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+      if (itn + gridDim.x < ntiles) {
+        cursor_gather(cs, ps_next, as_next);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+        cursor_advance(cs);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+      }
+    }
+    __syncthreads();  // A: h1 image complete
+
+    // ---------------------------------------------------------------- P2: z2 = b2 + W2^T h1^T ; head partial logits
+    f32x16 h2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const Frag b = read_row_frag(H1I, IMG_PLANE, rowB + 32 * s);
+      h2 = mfma3(W2a[s], b, h2);
+    }
+    uint32_t relu2 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      h2[q] = fmaxf(h2[q], 0.0f);
+      relu2 |= (h2[q] > 0.0f) ? (1u << q) : 0u;
+    }
+    {
+      half4 ph[4], pl[4];
+      if (ACTOR) {
+        write_image(H2I, r, 32 * w + 4 * h, h2, ph, pl);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            _Float16 a, b;
+            split1(h2[4 * g + e], a, b);
+            ph[g][e] = a;
+            pl[g][e] = b;
+          }
+      }
+      f32x16 yacc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) yacc[q] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag b;
+        b.hi = __builtin_shufflevector(ph[2 * s], ph[2 * s + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        b.lo = __builtin_shufflevector(pl[2 * s], pl[2 * s + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        yacc = mfma3(W3h[s], b, yacc);
+      }
+      // partial logits of this wave: register q of lane (row r, half h) is output (q&3) + 8(q>>2) + 4h
+      if (ACTOR) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+          if ((q & 3) + 8 * (q >> 2) < NO) {
+            if (o < NO) YP[(w * 32 + r) * (NO + 1) + o] = yacc[q] * W3_UNSCALE;
+          }
+        }
+      } else {
+        if (h == 0) YP[(w * 32 + r) * (NO + 1)] = yacc[0] * W3_UNSCALE;
+      }
+    }
+    __syncthreads();  // B: partial logits (and the h2 image) complete
+
+    // ---------------------------------------------------------------- P3: loss, d loss / d logits (x R), dz2
+    f32x16 dz;
+    if (ACTOR) {
+      const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int row = loss_row(q);
+        const bool rvalid = (it * 32 + row) < R;
+        const float* yp = YP + row * (NO + 1) + lo;
+        const float y = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[lo];
+        // masked Categorical over the NO lanes of the row (networks.py:116-124, distributions.py:146-165)
+        const bool legal = (lo < no) && (r_m[q] != 0u);
+        const float z = legal ? y : -FLT_MAX;
+        auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
+        auto add_op = [](float a, float b) { return a + b; };
+        const float mx = group_allreduce<NO>(z, fmax_op);
+        const float se = group_allreduce<NO>(expf(z - mx), add_op);
+        const float logp = z - (mx + logf(se));
+        const float pr = expf(logp);
+        const float ent = group_allreduce<NO>((pr > 0.0f) ? -(pr * logp) : 0.0f, add_op);
+        const int act = r_act[q];
+        const float lp = group_allreduce<NO>((lo == act) ? logp : 0.0f, add_op);
+        const float gae = (r_f1[q] - adv_mean) * adv_rstd;
+        const float ratio = expf(lp - r_f0[q]);
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+        const float l1 = ratio * gae, l2 = rc * gae;
+        const float pg = -fminf(l1, l2);
+        const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
+        const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+        const float g2 = inside ? (1.0f - g1) : 0.0f;
+        const float dlp = rvalid ? (-(g1 + g2) * gae * ratio) : 0.0f;  // x R: the 1/R of .mean() is applied at the end
+        const float ec = rvalid ? tk.ent_coef : 0.0f;
+        const float oh = (lo == act) ? 1.0f : 0.0f;
+        const float pl2 = (pr > 0.0f) ? logp : 0.0f;
+        float dyo = dlp * (oh - pr) + ec * pr * (pl2 + ent);
+        if (z == -FLT_MAX) dyo = 0.0f;
+        _Float16 da, db;
+        split1(dyo, da, db);
+        *reinterpret_cast<_Float16*>(DYI + row * DY_ROW + 2 * lo) = da;
+        *reinterpret_cast<_Float16*>(DYI + DY_PLANE + row * DY_ROW + 2 * lo) = db;
+        ab3 += dyo;
+        if (rvalid && lo == 0) {
+          loss_a += pg * invR;
+          loss_b += ent * invR;
+        }
+      }
+      __syncthreads();  // B2: dy of all 32 rows visible
+      // dz2^T[f][row] = sum_o W3[f][o] dy[row][o]: one 16-output step
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dz[q] = 0.0f;
+      {
+        const Frag b = read_row_frag(DYI, DY_PLANE, r * DY_ROW + 16 * h);
+        dz = mfma3(W3d, b, dz);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        dz[q] = ((relu2 >> q) & 1u) ? dz[q] * W3_UNSCALE : 0.0f;
+        ab2[q] += dz[q];
+      }
+    } else {
+      const float* yp = YP + r * (NO + 1);
+      const float v = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[0];
+      const float ov = r_f0[0], tg = r_f1[0];
+      const float diff = v - ov;
+      const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+      const float e1 = v - tg, e2 = vclip - tg;
+      const float l1 = e1 * e1, l2 = e2 * e2;
+      const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+      const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+      const float g2 = inside ? (1.0f - g1) : 0.0f;
+      float dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2)) : 0.0f;  // x R
+      if (tk.agg > 1) {
+        const bool mine = valid && slot < tk.agg;
+        dy0 = mine ? dy0 : 0.0f;
+        if (mine) {
+          loss_a += 0.5f * fmaxf(l1, l2) * invR;
+          ab3 += dy0;
+        }
+        AGG[slot * 33 + r] = dy0;
+        __syncthreads();  // B2
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) sum += AGG[a * 33 + r];  // fixed order: identical in every lane
+        dy0 = sum;
+      } else if (valid && w == 0 && h == 0) {
+        loss_a += 0.5f * fmaxf(l1, l2) * invR;
+        ab3 += dy0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        dz[q] = (h2[q] > 0.0f) ? (w3v[q] * dy0) : 0.0f;
+        ab2[q] += dz[q];
+        aW3r[q] = fmaf(h2[q], dy0, aW3r[q]);
+      }
+    }
+    {
+      half4 ph[4], pl[4];
+      write_image(DZ2I, r, 32 * w + 4 * h, dz, ph, pl);
+    }
+    __syncthreads();  // C: dz2 image complete
+
+    // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW3, dW2
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const Frag b = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * s);
+      acc = mfma3(W2b[s], b, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
+    {
+      half4 ph[4], pl[4];
+      write_image(DZ1I, r, 32 * w + 4 * h, acc, ph, pl);
+    }
+    // next tile's x rows have arrived long ago: split + store them into the other buffer (read from barrier D on)
+    if (have_next) stage_commit(buf ^ 1, xr);
+    if (ACTOR) {
+      // gW3^T[o][f = 32w + r] += sum_rows dy[row][o] h2[row][f]   (outputs >= NO of the dy image are zero)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const Frag a = read_tr_frag(DYI + trD + 16 * s * DY_ROW, DY_PLANE, DY_ROW);
+        const Frag b = read_tr_frag(H2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+        gW3 = mfma3(a, b, gW3);
+      }
+    }
+    // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const Frag b = read_tr_frag(DZ2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const Frag a = read_tr_frag(H1I + trI + 16 * s * IMG_ROW + 2 * (32 * t), IMG_PLANE, IMG_ROW);
+        gW2[t] = mfma3(a, b, gW2[t]);
+      }
+    }
+    __syncthreads();  // D: dz1 image (and the next x tile) complete
+    // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const Frag b = read_tr_frag(DZ1I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+#pragma unroll
+      for (int t = 0; t < KT1; ++t) {
+        const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);
+        gW1[t] = mfma3(a, b, gW1[t]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; r_m[q] = n_m[q]; }
+    // no barrier here: the next tile's P1 writes the h1 image, whose last readers (gW2) sit before barrier D, and
+    // reads the other x buffer, complete since D; every other image is rewritten only behind barriers A..C
+  }
+
+  // ------------------------------------------------------------------ epilogue: one slab per block (x 1/R)
+  __syncthreads();
+  float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
+  const int oB2 = mlp_off_b2(din), oB3 = mlp_off_b3(din, no);
+  const int Pn = mlp_param_count(din, no);
+#pragma unroll
+  for (int t = 0; t < KT1; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = mlp_feat(t, q, h);
+      if (k <= din) slab[k * MLP_H + 32 * w + r] = gW1[t][q] * invR;  // row din = db1
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) slab[oW2 + mlp_feat(t, q, h) * MLP_H + 32 * w + r] = gW2[t][q] * invR;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float v = ab2[q];
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (r == 0) slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
+  }
+  float* red = YP;  // epilogue scratch (the tile loop is over)
+  if (ACTOR) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (o < no) slab[oW3 + (32 * w + r) * no + o] = gW3[q] * invR;
+    }
+    float v = ab3;
+#pragma unroll
+    for (int m = NO; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane < NO) red[w * NO + lane] = v;
+    for (int o = 32; o > 0; o >>= 1) {
+      loss_a += __shfl_down(loss_a, o, 64);
+      loss_b += __shfl_down(loss_b, o, 64);
+    }
+    if (lane == 0) { red[4 * NO + 2 * w] = loss_a; red[4 * NO + 2 * w + 1] = loss_b; }
+    __syncthreads();
+    if (tid < no) slab[oB3 + tid] = (((red[tid] + red[NO + tid]) + red[2 * NO + tid]) + red[3 * NO + tid]) * invR;
+    if (tid == 0) {
+      slab[Pn] = ((red[4 * NO] + red[4 * NO + 2]) + red[4 * NO + 4]) + red[4 * NO + 6];
+      slab[Pn + 1] = ((red[4 * NO + 1] + red[4 * NO + 3]) + red[4 * NO + 5]) + red[4 * NO + 7];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float v = aW3r[q];
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (r == 0) slab[oW3 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
+    }
+    float v = ab3, l = loss_a;
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_down(v, o, 64);
+      l += __shfl_down(l, o, 64);
+    }
+    if (lane == 0) { red[2 * w] = v; red[2 * w + 1] = l; }
+    __syncthreads();
+    if (tid == 0) {
+      slab[oB3] = (((red[0] + red[2]) + red[4]) + red[6]) * invR;
+      slab[Pn] = ((red[1] + red[3]) + red[5]) + red[7];
+      slab[Pn + 1] = 0.0f;
+    }
+  }
+}
+
+template <int NO, int S1, bool ACTOR>
+int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
+  const H2Layout L = make_h2_layout<NO, S1>(ACTOR);
+  MAVA_ARG_CHECK(L.end <= 163840, 8, "ppo_train_h2: %d bytes of LDS exceed the 160 KiB of a CU", L.end);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_h2_kernel<NO, S1, ACTOR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.end));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR>), dim3(n_slab), dim3(256), L.end, s, tk, L);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+template <int NO, bool ACTOR>
+int dispatch_s1(const TrainTask& tk, int n_slab, hipStream_t s) {
+  const int s1 = (tk.din + 1 + 15) / 16;  // 16-input steps of layer 1, including the ones (bias) column
+  switch (s1) {
+#ifndef MAVA_FAST_BUILD
+    case 1: return launch_h2<NO, 1, ACTOR>(tk, n_slab, s);
+    case 2: return launch_h2<NO, 2, ACTOR>(tk, n_slab, s);
+    case 3: return launch_h2<NO, 3, ACTOR>(tk, n_slab, s);
+    case 4: return launch_h2<NO, 4, ACTOR>(tk, n_slab, s);
+    case 6: return launch_h2<NO, 6, ACTOR>(tk, n_slab, s);
+#endif
+    case 5: return launch_h2<NO, 5, ACTOR>(tk, n_slab, s);
+    default: return 1;  // not instantiated: the caller runs the exact-f32 kernel
+  }
+}
+
+}  // namespace
+
+static long g_h2_launches = 0;
+// Diagnostic (not part of include/mava_hip.h): launches that really ran on the split-f16 kernel.
+extern "C" long mava_debug_h2_launches(void) { return g_h2_launches; }
+
+static int h2_dispatch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
+  if (actor) {
+    if (tk.action_f != nullptr) return 1;  // continuous head: exact-f32 kernel
+    if (tk.no <= 8) return dispatch_s1<8, true>(tk, n_slab, s);
+    if (tk.no <= 16) return dispatch_s1<16, true>(tk, n_slab, s);
+    return dispatch_s1<32, true>(tk, n_slab, s);
+  }
+  return dispatch_s1<1, false>(tk, n_slab, s);
+}
+
+int mava_train_h2_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
+  const int rc = h2_dispatch(tk, n_slab, actor, s);
+  if (rc == 0) ++g_h2_launches;
+  return rc;
+}

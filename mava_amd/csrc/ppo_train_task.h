@@ -1,0 +1,36 @@
+// Arguments of one fused PPO minibatch launch, shared by the exact-f32 kernel (ppo_train.hip) and the
+// split-f16 kernel (ppo_train_h2.hip).
+#pragma once
+#include <stdint.h>
+
+#include "common.h"
+
+struct TrainTask {
+  const float* params;
+  const float* x;          // (rows_x, din)
+  int din, no, xshare, xv;
+  int A;                   // agent rows per (t,e) index
+  int agg;                 // critic only: 1, or A when the A agents of an index share one input row and are
+                           // aggregated into it (one network pass per (t,e) row instead of A identical ones)
+  const int32_t* idx;      // minibatch (t*E+e) indices, or null => idx_base + b
+  long idx_base;
+  int Rb;                  // (t,e) rows in the minibatch; agent rows R = Rb * A
+  const uint8_t* mask;     // (TE*A, no) or null
+  const int32_t* action;   // (TE*A)
+  const float* action_f;   // continuous head: (TE*A, no) actions in (-1, 1); the raw scales follow the MLP in params
+  uint32_t seed_lo, seed_hi, ent_step, row_offset;  // continuous head: Philox key / counters of the entropy sample
+  const float* old_logp;   // (TE*A)
+  const float* adv;        // (TE*A)
+  const double* stats;     // STATS_BLOCKS x {sum, sumsq} partials of the minibatch advantages
+  const float* old_value;  // (TE*A)
+  const float* targets;    // (TE*A)
+  float clip_eps, ent_coef, vf_coef;
+  float* slab;
+  long slab_stride;
+  unsigned long long* stamps;  // diagnostic builds only (-DMAVA_STAMPS): per-phase cycle sums of block 0
+};
+
+// ppo_train_h2.hip: the same fused kernel on v_mfma_f32_32x32x16_f16 with every operand split into two f16 terms
+// (hi + lo, f32 accumulation).  Returns MAVA_OK, or 1 when the shape is not instantiated (the caller then runs the
+// exact-f32 kernel), or a negative error code.
+int mava_train_h2_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s);

@@ -223,6 +223,22 @@ def test_policy_sampling_distribution(dev):
 
 
 # ---------------------------------------------------------------------------- PPO gradient kernels
+@pytest.fixture(params=[0, 1], ids=["f32", "f16x2"])
+def matmul_mode(request):
+    """0: exact-f32 MFMA kernels (ppo_train.hip); 1: split-f16 operands (ppo_train_h2.hip) for the shapes it
+    instantiates (others fall back to the exact kernel).  Yields (mode, launches-on-the-f16x2-kernel counter)."""
+    import ctypes
+
+    from mava_amd._lib import lib
+
+    L = lib()
+    L.mava_debug_h2_launches.restype = ctypes.c_long
+    L.mava_ppo_set_matmul_mode(request.param)
+    before = L.mava_debug_h2_launches()
+    yield request.param, (lambda: L.mava_debug_h2_launches() - before)
+    L.mava_ppo_set_matmul_mode(0)
+
+
 def _traj(rng, TE, A, O, nA, shared_gs=True):
     rows = TE * A
     av = rng.standard_normal((rows, O + A)).astype(np.float32)
@@ -239,8 +255,9 @@ def _traj(rng, TE, A, O, nA, shared_gs=True):
 
 @pytest.mark.parametrize("TE,A,O,nA,Rb,use_idx,n_slab", [(64, 4, 66, 5, 64, False, 3), (200, 4, 66, 5, 77, True, 8),
                                                           (96, 2, 30, 14, 40, True, 2), (33, 1, 7, 3, 33, True, 1),
-                                                          (4096, 4, 66, 5, 2048, True, 256)])
-def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab):
+                                                          (4096, 4, 66, 5, 2048, True, 256),
+                                                          (4096, 4, 66, 5, 4096, True, 16)])  # 32 tiles per block
+def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmul_mode):
     from mava_amd import ops
     from oracle import torch_ref
 
@@ -278,14 +295,18 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab):
     # north_star: PPO gradients within 1e-4 rtol (tolerance form of BASELINE.md §2)
     assert_close(got[:P], g, 1e-4, "actor grad")
     assert_close(got[P:], np.array([la, ent]), 1e-5, "actor loss/entropy", scale=1.0)
+    if matmul_mode[0] == 1:
+        assert matmul_mode[1]() == 1, "the f16x2 kernel did not run for this shape"
 
 
 @pytest.mark.parametrize("TE,A,O,Rb,use_idx,shared,n_slab", [(64, 4, 66, 64, False, True, 3), (200, 4, 66, 77, True, True, 8),
                                                              (96, 2, 30, 40, True, False, 2), (33, 1, 9, 33, True, True, 1),
                                                              (4096, 4, 66, 2048, True, True, 256),
-                                                             (150, 8, 20, 101, True, True, 5), (70, 2, 50, 70, False, True, 4)])
+                                                             (150, 8, 20, 101, True, True, 5), (70, 2, 50, 70, False, True, 4),
+                                                             (4096, 4, 66, 4096, True, True, 16),  # 8 / 32 tiles per block
+                                                             (2048, 4, 66, 2048, True, True, 4)])
 @pytest.mark.parametrize("agg", [1, 0])
-def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, agg):
+def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, agg, matmul_mode):
     """agg=1: agents that share one critic input row are aggregated (one network pass per (t,e) row, the sum of
     their loss gradients back-propagated); agg=0: one pass per agent row.  Both must match the oracle, which
     follows the reference and evaluates every agent row."""
@@ -328,9 +349,11 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
     assert_close(g, g2, 1e-9, "oracle vs torch autograd")
     assert_close(got[:P], g, 1e-4, "critic grad")
     assert_close(got[P:P + 1], np.array([vl]), 1e-5, "value loss", scale=1.0)
+    if matmul_mode[0] == 1:  # input widths up to 95 run on the f16x2 kernel, wider ones fall back to exact f32
+        assert matmul_mode[1]() == (1 if din <= 95 else 0)
 
 
-def test_train_kernels_full_launch_shape(dev):
+def test_train_kernels_full_launch_shape(dev, matmul_mode):
     """BASELINE config 2's REAL launch shape: one minibatch of Rb = 262 144 (t,e) indices out of T*E = 524 288,
     A = 4 -> 1 048 576 agent rows, 256 slabs (one persistent block per CU), 32-bit row cursors over the 2 M-row
     trajectory - against the float64 oracle evaluated in chunks (oracle/ppo_oracle.py part_of / R_total).

@@ -13,7 +13,8 @@ from typing import Optional
 import torch  # noqa: F401  (must precede loading libmavahip.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmavahip.so")
+# MAVA_LIB_PATH: a diagnostic build of the same library (e.g. -DMAVA_STAMPS, tools/train_stamps.py); never a fallback
+LIB_PATH = os.environ.get("MAVA_LIB_PATH") or os.path.join(_HERE, "libmavahip.so")
 
 _lib: Optional[C.CDLL] = None
 

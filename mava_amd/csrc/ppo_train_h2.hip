@@ -45,6 +45,21 @@ constexpr int DY_ROW = 80;         // [32 rows][32 outputs] f16 + 16
 constexpr int DY_PLANE = 32 * DY_ROW;
 constexpr float W3_SCALE = 128.0f, W3_UNSCALE = 1.0f / 128.0f;
 
+#ifdef MAVA_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                                  \
+    st_prev = st_now;                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 struct Frag {  // one split MFMA operand: 8 k-values per lane as hi + lo
   half8 hi, lo;
 };
@@ -128,38 +143,61 @@ __device__ __forceinline__ float group_allreduce(float v, Op op) {
 }
 
 struct H2Layout {  // byte offsets into the dynamic LDS array (all multiples of 16)
-  int h1, dz2, dz1, h2, xs, xs_plane, xs_row, dy, yp, agg, small, end;
+  int h1, dz2, dz1, w2, xs, xs_plane, xs_row, dy, yp, agg, small, end;
 };
 
-template <int NO, int S1>
+// WIDE (input width > 95): the layer-1 weights stream from a pre-split global copy through a register ring and the
+// x tile is single-buffered; otherwise W1 is register-resident and the x tile double-buffered.
+template <int NO, int S1, bool WIDE>
 H2Layout make_h2_layout(bool actor) {
   constexpr int KT1 = (S1 + 1) / 2;
   H2Layout L;
   L.h1 = 0;
   L.dz2 = L.h1 + IMG_BYTES;
-  L.dz1 = L.dz2 + IMG_BYTES;
-  L.h2 = L.dz1 + IMG_BYTES;  // actor only (B operand of dy^T.h2)
-  L.xs = L.h2 + (actor ? IMG_BYTES : 0);
+  L.dz1 = L.dz2 + IMG_BYTES;  // also the h2 image (actor): h2's last reader (dy^T.h2) runs before barrier C, dz1 is written behind it
+  L.w2 = L.dz1 + IMG_BYTES;   // W2 [128 k][128 n]: row reads for dh1 = W2.dz2, transposed reads for layer 2
+  L.xs = L.w2 + 4 * IMG_BYTES;
   L.xs_row = 2 * 32 * KT1 + 16;  // [32 rows][32*KT1 inputs] f16 + 16: an odd number of 16-byte slots
   L.xs_plane = 32 * L.xs_row;
-  L.dy = L.xs + 2 * 2 * L.xs_plane;  // two buffers x (hi, lo)
-  L.yp = L.dy + 2 * DY_PLANE;
-  L.agg = L.yp + 4 * 32 * (NO + 1) * 4;
-  L.agg = (L.agg + 15) & ~15;
-  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[NO] | misc[16]
+  L.dy = L.xs + (WIDE ? 1 : 2) * 2 * L.xs_plane;  // buffers x (hi, lo)
+  // partial logits (f32) live inside an image that is idle between barriers A and B2: dz2's (actor), dz1's (critic)
+  L.yp = actor ? L.dz2 : L.dz1;
+  L.agg = L.dy + (actor ? 2 * DY_PLANE : 0);
+  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[32] | misc[16]
   L.small = (L.small + 15) & ~15;
   L.end = L.small + (128 + 32 + 16) * 4;
   return L;
 }
+constexpr int W2_PLANE = 128 * IMG_ROW;
+constexpr int W1_RING = 6;  // WIDE: register ring depth in 16-input steps (S1 is padded to a multiple of it)
 
-template <int NO, int S1, bool ACTOR>
-__global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2Layout L) {
+// WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
+// lane (r, h) of wave w holds W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din zero.
+__global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, int steps, uint4* __restrict__ out) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= steps * 256) return;
+  const int s = gid >> 8, w = (gid >> 6) & 3, lane = gid & 63, r = lane & 31, h = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * s + 8 * h + e;
+    v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+  }
+  const Frag f = split8(v);
+  out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
+  out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
+}
+
+template <int NO, int S1, bool ACTOR, bool WIDE, int XV>
+__global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2Layout L, const uint4* __restrict__ w1p) {
+  static_assert(!WIDE || S1 % W1_RING == 0, "WIDE: S1 must be a multiple of the W1 ring depth");
   constexpr int KT1 = (S1 + 1) / 2;  // 32-input tiles of the layer-1 weight gradient
   extern __shared__ __attribute__((aligned(16))) u8 lds[];
   u8* const H1I = lds + L.h1;
   u8* const DZ2I = lds + L.dz2;
   u8* const DZ1I = lds + L.dz1;
-  u8* const H2I = lds + L.h2;
+  u8* const H2I = lds + L.dz1;  // alias, see make_h2_layout
+  u8* const W2I = lds + L.w2;
   u8* const DYI = lds + L.dy;
   float* const YP = reinterpret_cast<float*>(lds + L.yp);
   float* const AGG = reinterpret_cast<float*>(lds + L.agg);
@@ -174,19 +212,34 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   const int din = tk.din, no = tk.no;
   const long R = (!ACTOR && tk.agg > 1) ? (long)tk.Rb : (long)tk.Rb * tk.A;
   const float invR = 1.0f / (float)((long)tk.Rb * tk.A);
-  constexpr int NR = (32 * KT1 + 7) / 8;  // staged floats per thread (scalar pieces, 8 threads per row)
+  constexpr int NPC = (32 * KT1 / XV + 7) / 8;  // staged pieces (XV floats each) per thread, 8 threads per row
+  constexpr int NR = NPC * XV;
 
   // ---------------------------------------------------------------- prologue: LDS images, small vectors
   for (int i = tid * 16; i < L.end; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
   __syncthreads();
+  const float* const P = tk.params;
+  const int oW2 = mlp_off_w2(din), oW3 = mlp_off_w3(din);
   {
-    const float* p = tk.params;
-    if (tid < 128) B2s[tid] = p[mlp_off_b2(din) + tid];
-    if (tid < no) B3s[tid] = p[mlp_off_b3(din, no) + tid];
-    // the ones column of both x buffers: "row din" of W1 in the flat parameter vector is b1
-    if (tid < 64) {
+    if (tid < 128) B2s[tid] = P[mlp_off_b2(din) + tid];
+    if (tid < no) B3s[tid] = P[mlp_off_b3(din, no) + tid];
+    // the ones column of the x buffers: "row din" of W1 in the flat parameter vector is b1
+    if (tid < (WIDE ? 32 : 64)) {
       const int b = tid >> 5, row = tid & 31;
       *reinterpret_cast<_Float16*>(lds + L.xs + b * 2 * xs_plane + row * xs_row + 2 * din) = (_Float16)1.0f;
+    }
+    // W2 image: thread t converts rows k = t / 2, t / 2 + ... : 16384 elements, 64 per thread, 4 at a time
+    for (int i = tid; i < 128 * 32; i += 256) {
+      const int k = i >> 5, c4 = i & 31;
+      const float4 v = *reinterpret_cast<const float4*>(P + oW2 + k * MLP_H + 4 * c4);
+      half4 a, b;
+      _Float16 x0, x1;
+      split1(v.x, x0, x1); a[0] = x0; b[0] = x1;
+      split1(v.y, x0, x1); a[1] = x0; b[1] = x1;
+      split1(v.z, x0, x1); a[2] = x0; b[2] = x1;
+      split1(v.w, x0, x1); a[3] = x0; b[3] = x1;
+      *reinterpret_cast<half4*>(W2I + k * IMG_ROW + 8 * c4) = a;
+      *reinterpret_cast<half4*>(W2I + W2_PLANE + k * IMG_ROW + 8 * c4) = b;
     }
     if (ACTOR && tid == 0) {
       // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
@@ -199,32 +252,31 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       misc[1] = 1.0f / ((float)sqrt(var) + 1e-8f);
     }
   }
-  // ---------------------------------------------------------------- weight fragments, split once, register-resident
-  const float* const P = tk.params;
-  const int oW2 = mlp_off_w2(din), oW3 = mlp_off_w3(din);
-  Frag W1f[S1];  // A of layer 1: W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din is zero
+  // ---------------------------------------------------------------- weight fragments kept in registers
+  // layer 1 (A operand): W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din is zero.  Narrow inputs: all S1
+  // steps resident; WIDE: a ring of W1_RING steps fed from the pre-split global copy.
+  constexpr int NW1 = WIDE ? W1_RING : S1;
+  Frag W1f[NW1];
+  const uint4* const w1p_lane = w1p + 2 * (w * 64 + lane);  // + 2 * 256 * s
+  auto w1_fetch = [&](int s) -> Frag {
+    Frag f;
+    f.hi = __builtin_bit_cast(half8, w1p_lane[512 * s]);
+    f.lo = __builtin_bit_cast(half8, w1p_lane[512 * s + 1]);
+    return f;
+  };
 #pragma unroll
-  for (int s = 0; s < S1; ++s) {
-    float v[8];
+  for (int s = 0; s < NW1; ++s) {
+    if (WIDE) {
+      W1f[s] = w1_fetch(s);
+    } else {
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 16 * s + 8 * h + e;
-      v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * h + e;
+        v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+      }
+      W1f[s] = split8(v);
     }
-    W1f[s] = split8(v);
-  }
-  Frag W2a[8];  // A of layer 2: W2[k = 16s + 8h + e][f = 32w + r]
-  Frag W2b[8];  // A of dh1 = W2 . dz2: W2[k = 32w + r][n = 16s + 8h + e]
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = P[oW2 + (16 * s + 8 * h + e) * MLP_H + 32 * w + r];
-    W2a[s] = split8(v);
-    const float4 b0 = *reinterpret_cast<const float4*>(P + oW2 + (32 * w + r) * MLP_H + 16 * s + 8 * h);
-    const float4 b1 = *reinterpret_cast<const float4*>(P + oW2 + (32 * w + r) * MLP_H + 16 * s + 8 * h + 4);
-    const float u[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    W2b[s] = split8(u);
   }
   // head: logits^T[o = r][row] += sum over the wave's 32 features, B = the layer-2 accumulator itself: element e of
   // lane half h in k-step s is feature 32w + 16s + 8(e>>2) + 4h + (e&3)
@@ -324,27 +376,54 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     const uint32_t fr = (uint32_t)p_raw * Au + a;
     return (tk.xshare == 1) ? fr : ((uint32_t)tk.xshare == Au ? (uint32_t)p_raw : fr / (uint32_t)tk.xshare);
   };
-  // x staging: thread l8 of a row takes the scalar pieces l8, l8 + 8, ...; a piece past the row end is loaded from the
+  // x staging: thread l8 of a row takes the XV-float pieces l8, l8 + 8, ...; a piece past the row end is loaded from the
   // row start and stored to a dummy slot (branch-free, see ppo_train.hip stage_load / stage_write)
+  const int nv = din / XV;  // pieces per row (XV > 1 only when din % XV == 0 and the rows are XV*4-byte aligned)
   auto stage_issue = [&](uint32_t xrow_idx, float (&xr)[NR]) {
     const float* xrow = tk.x + (long)xrow_idx * din;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const int c = l8 + 8 * i;
-      xr[i] = xrow[(c < din) ? c : 0];
+      const int cc = (c < nv) ? c : 0;
+      if (XV == 4) {
+        const float4 v = reinterpret_cast<const float4*>(xrow)[cc];
+        xr[4 * i] = v.x; xr[4 * i + 1] = v.y; xr[4 * i + 2] = v.z; xr[4 * i + 3] = v.w;
+      } else if (XV == 2) {
+        const float2 v = reinterpret_cast<const float2*>(xrow)[cc];
+        xr[2 * i] = v.x; xr[2 * i + 1] = v.y;
+      } else {
+        xr[i] = xrow[cc];
+      }
     }
   };
-  _Float16* const xs_dummy = reinterpret_cast<_Float16*>(misc + 8);
+  u8* const xs_dummy = reinterpret_cast<u8*>(misc + 8);  // 16 bytes nobody reads
   auto stage_commit = [&](int buf, const float (&xr)[NR]) {
     u8* base = lds + L.xs + buf * 2 * xs_plane + srow * xs_row;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const int c = l8 + 8 * i;
-      _Float16 a, b;
-      split1(xr[i], a, b);
-      const bool ok = c < din;
-      *(ok ? reinterpret_cast<_Float16*>(base + 2 * c) : xs_dummy) = a;
-      *(ok ? reinterpret_cast<_Float16*>(base + xs_plane + 2 * c) : xs_dummy) = b;
+      const bool ok = c < nv;
+      u8* qa = ok ? (base + 2 * XV * c) : xs_dummy;
+      u8* qb = ok ? (base + xs_plane + 2 * XV * c) : xs_dummy;
+      if (XV == 4) {
+        half4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 x0, x1; split1(xr[4 * i + e], x0, x1); a[e] = x0; b[e] = x1; }
+        *reinterpret_cast<half4*>(qa) = a;
+        *reinterpret_cast<half4*>(qb) = b;
+      } else if (XV == 2) {
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        half2v a, b;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { _Float16 x0, x1; split1(xr[2 * i + e], x0, x1); a[e] = x0; b[e] = x1; }
+        *reinterpret_cast<half2v*>(qa) = a;
+        *reinterpret_cast<half2v*>(qb) = b;
+      } else {
+        _Float16 x0, x1;
+        split1(xr[i], x0, x1);
+        *reinterpret_cast<_Float16*>(qa) = x0;
+        *reinterpret_cast<_Float16*>(qb) = x1;
+      }
     }
   };
 
@@ -389,9 +468,12 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   const int trI = (8 * h + tq) * IMG_ROW + 2 * (16 * g1 + 4 * tp);  // + 16 s * IMG_ROW + 2 * (first column of the tile)
   const int trX = (8 * h + tq) * xs_row + 2 * (16 * g1 + 4 * tp);
   const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
+  const int w2row = (32 * w + r) * IMG_ROW + 16 * h;           // + 32 s: W2[32w + r][16s + 8h .. + 7]
   int buf = 0;
 
-  for (; it < ntiles; it += gridDim.x, buf ^= 1) {
+  STAMP_DECL
+  for (; it < ntiles; it += gridDim.x, buf ^= (WIDE ? 0 : 1)) {
+    STAMP(14);
     const bool valid = (it * 32 + r) < R;
     const long itn = it + gridDim.x;
     const bool have_next = itn < ntiles;
@@ -411,8 +493,14 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
 #pragma unroll
     for (int s = 0; s < S1; ++s) {
       const Frag b = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * s);
-      acc = mfma3(W1f[s], b, acc);
+      acc = mfma3(W1f[s % NW1], b, acc);
+      if (WIDE) {
+        // refill the slot consumed one step ago with step s - 1 + W1_RING (wrapping to the head steps of the next tile)
+        if (s >= 1) W1f[(s - 1) % NW1] = w1_fetch((s - 1 + W1_RING) % S1);
+      }
     }
+    if (WIDE) W1f[(S1 - 1) % NW1] = w1_fetch((S1 - 1 + W1_RING) % S1);
+    STAMP(0);
     uint32_t relu1 = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -423,7 +511,8 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       half4 ph[4], pl[4];
       write_image(H1I, r, 32 * w + 4 * h, acc, ph, pl);
     }
-    // next tile's gathers: issued after P1 (their latency hides under P2..P4), committed to the OTHER x buffer
+    STAMP(1);
+    // next tile's gathers: issued after P1 (their latency hides under P2..P4)
     if (have_next) {
       stage_issue(xrow_next, xr);
 #pragma unroll
@@ -437,7 +526,9 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
       }
     }
+    STAMP(2);
     __syncthreads();  // A: h1 image complete
+    STAMP(3);
 
     // ---------------------------------------------------------------- P2: z2 = b2 + W2^T h1^T ; head partial logits
     f32x16 h2;
@@ -445,9 +536,11 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+      const Frag a = read_tr_frag(W2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
       const Frag b = read_row_frag(H1I, IMG_PLANE, rowB + 32 * s);
-      h2 = mfma3(W2a[s], b, h2);
+      h2 = mfma3(a, b, h2);
     }
+    STAMP(4);
     uint32_t relu2 = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -492,9 +585,11 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         if (h == 0) YP[(w * 32 + r) * (NO + 1)] = yacc[0] * W3_UNSCALE;
       }
     }
+    STAMP(5);
     __syncthreads();  // B: partial logits (and the h2 image) complete
+    STAMP(6);
 
-    // ---------------------------------------------------------------- P3: loss, d loss / d logits (x R), dz2
+    // ---------------------------------------------------------------- P3: loss, d loss / d logits (x R), dW3, dz2
     f32x16 dz;
     if (ACTOR) {
       const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
@@ -540,7 +635,15 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
           loss_b += ent * invR;
         }
       }
-      __syncthreads();  // B2: dy of all 32 rows visible
+      STAMP(7);
+      __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
+      // gW3^T[o][f = 32w + r] += sum_rows dy[row][o] h2[row][f]   (outputs >= NO of the dy image are zero)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const Frag a = read_tr_frag(DYI + trD + 16 * s * DY_ROW, DY_PLANE, DY_ROW);
+        const Frag b = read_tr_frag(H2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+        gW3 = mfma3(a, b, gW3);
+      }
       // dz2^T[f][row] = sum_o W3[f][o] dy[row][o]: one 16-output step
 #pragma unroll
       for (int q = 0; q < 16; ++q) dz[q] = 0.0f;
@@ -573,6 +676,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
           ab3 += dy0;
         }
         AGG[slot * 33 + r] = dy0;
+        STAMP(7);
         __syncthreads();  // B2
         float sum = 0.0f;
 #pragma unroll
@@ -584,7 +688,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        dz[q] = (h2[q] > 0.0f) ? (w3v[q] * dy0) : 0.0f;
+        dz[q] = ((relu2 >> q) & 1u) ? (w3v[q] * dy0) : 0.0f;
         ab2[q] += dz[q];
         aW3r[q] = fmaf(h2[q], dy0, aW3r[q]);
       }
@@ -593,15 +697,18 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       half4 ph[4], pl[4];
       write_image(DZ2I, r, 32 * w + 4 * h, dz, ph, pl);
     }
-    __syncthreads();  // C: dz2 image complete
+    STAMP(8);
+    __syncthreads();  // C: dz2 image complete; the h2 image is free (it becomes dz1's)
+    STAMP(9);
 
-    // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW3, dW2
+    // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW2
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+      const Frag a = read_row_frag(W2I, W2_PLANE, w2row + 32 * s);
       const Frag b = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * s);
-      acc = mfma3(W2b[s], b, acc);
+      acc = mfma3(a, b, acc);
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
@@ -609,17 +716,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       half4 ph[4], pl[4];
       write_image(DZ1I, r, 32 * w + 4 * h, acc, ph, pl);
     }
-    // next tile's x rows have arrived long ago: split + store them into the other buffer (read from barrier D on)
-    if (have_next) stage_commit(buf ^ 1, xr);
-    if (ACTOR) {
-      // gW3^T[o][f = 32w + r] += sum_rows dy[row][o] h2[row][f]   (outputs >= NO of the dy image are zero)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const Frag a = read_tr_frag(DYI + trD + 16 * s * DY_ROW, DY_PLANE, DY_ROW);
-        const Frag b = read_tr_frag(H2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
-        gW3 = mfma3(a, b, gW3);
-      }
-    }
+    // narrow inputs: the next tile's x rows have arrived long ago - split + store them into the other buffer (read
+    // from barrier D on)
+    if (!WIDE && have_next) stage_commit(buf ^ 1, xr);
+    STAMP(10);
     // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -630,7 +730,9 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         gW2[t] = mfma3(a, b, gW2[t]);
       }
     }
+    STAMP(11);
     __syncthreads();  // D: dz1 image (and the next x tile) complete
+    STAMP(12);
     // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -641,11 +743,22 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         gW1[t] = mfma3(a, b, gW1[t]);
       }
     }
+    STAMP(13);
+    if (WIDE) {
+      __syncthreads();  // E: every reader of the (single) x tile is done
+      if (have_next) stage_commit(0, xr);
+      __syncthreads();  // F: next x tile visible
+    }
 #pragma unroll
     for (int q = 0; q < NP; ++q) { r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; r_m[q] = n_m[q]; }
-    // no barrier here: the next tile's P1 writes the h1 image, whose last readers (gW2) sit before barrier D, and
-    // reads the other x buffer, complete since D; every other image is rewritten only behind barriers A..C
+    // narrow inputs: no barrier here - the next tile's P1 writes the h1 image, whose last readers (gW2) sit before
+    // barrier D, and reads the other x buffer, complete since D; every other image is rewritten only behind barriers A..C
   }
+#ifdef MAVA_STAMPS
+  if (tk.stamps != nullptr && blockIdx.x == 0 && lane == 0) {
+    for (int i = 0; i < 16; ++i) tk.stamps[w * 16 + i] = st_acc[i];
+  }
+#endif
 
   // ------------------------------------------------------------------ epilogue: one slab per block (x 1/R)
   __syncthreads();
@@ -670,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
     if (r == 0) slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
   }
-  float* red = YP;  // epilogue scratch (the tile loop is over)
+  float* red = reinterpret_cast<float*>(lds + L.h1);  // epilogue scratch (the tile loop is over)
   if (ACTOR) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -715,19 +828,42 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   }
 }
 
-template <int NO, int S1, bool ACTOR>
+// WIDE launches: one pre-split copy of W1 per network kind, allocated on first use and kept for the process
+// (18 steps x 256 lanes x 32 bytes = 147 KB); filled by pack_w1_kernel on the launch stream ahead of every launch.
+uint4* g_w1p[2] = {nullptr, nullptr};
+
+template <int NO, int S1, bool ACTOR, bool WIDE, int XV>
 int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
-  const H2Layout L = make_h2_layout<NO, S1>(ACTOR);
+  const H2Layout L = make_h2_layout<NO, S1, WIDE>(ACTOR);
   MAVA_ARG_CHECK(L.end <= 163840, 8, "ppo_train_h2: %d bytes of LDS exceed the 160 KiB of a CU", L.end);
   static bool attr_set = false;
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_h2_kernel<NO, S1, ACTOR>,
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_h2_kernel<NO, S1, ACTOR, WIDE, XV>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, L.end));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR>), dim3(n_slab), dim3(256), L.end, s, tk, L);
+  const uint4* w1p = nullptr;
+  if (WIDE) {
+    uint4*& buf = g_w1p[ACTOR ? 0 : 1];
+    if (buf == nullptr) MAVA_HIP_CHECK(hipMalloc((void**)&buf, (size_t)18 * 256 * 32));
+    hipLaunchKernelGGL(pack_w1_kernel, dim3(S1), dim3(256), 0, s, tk.params, tk.din, S1, buf);
+    MAVA_LAUNCH_CHECK();
+    w1p = buf;
+  }
+  hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR, WIDE, XV>), dim3(n_slab), dim3(256), L.end, s, tk, L, w1p);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
+}
+
+template <int NO, int S1, bool ACTOR, bool WIDE>
+int dispatch_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
+  const uintptr_t a = (uintptr_t)tk.x;
+  if constexpr (WIDE) {
+    if (tk.din % 4 == 0 && a % 16 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 4>(tk, n_slab, s);
+  } else {
+    if (tk.din % 2 == 0 && a % 8 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 2>(tk, n_slab, s);
+  }
+  return launch_h2<NO, S1, ACTOR, WIDE, 1>(tk, n_slab, s);
 }
 
 template <int NO, bool ACTOR>
@@ -735,14 +871,16 @@ int dispatch_s1(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int s1 = (tk.din + 1 + 15) / 16;  // 16-input steps of layer 1, including the ones (bias) column
   switch (s1) {
 #ifndef MAVA_FAST_BUILD
-    case 1: return launch_h2<NO, 1, ACTOR>(tk, n_slab, s);
-    case 2: return launch_h2<NO, 2, ACTOR>(tk, n_slab, s);
-    case 3: return launch_h2<NO, 3, ACTOR>(tk, n_slab, s);
-    case 4: return launch_h2<NO, 4, ACTOR>(tk, n_slab, s);
-    case 6: return launch_h2<NO, 6, ACTOR>(tk, n_slab, s);
+    case 1: return dispatch_xv<NO, 1, ACTOR, false>(tk, n_slab, s);
+    case 2: return dispatch_xv<NO, 2, ACTOR, false>(tk, n_slab, s);
+    case 3: return dispatch_xv<NO, 3, ACTOR, false>(tk, n_slab, s);
+    case 4: return dispatch_xv<NO, 4, ACTOR, false>(tk, n_slab, s);
+    case 6: return dispatch_xv<NO, 6, ACTOR, false>(tk, n_slab, s);
+    case 7: case 8: case 9: case 10: case 11: case 12: return dispatch_xv<NO, 12, ACTOR, true>(tk, n_slab, s);
 #endif
-    case 5: return launch_h2<NO, 5, ACTOR>(tk, n_slab, s);
-    default: return 1;  // not instantiated: the caller runs the exact-f32 kernel
+    case 5: return dispatch_xv<NO, 5, ACTOR, false>(tk, n_slab, s);
+    case 13: case 14: case 15: case 16: case 17: case 18: return dispatch_xv<NO, 18, ACTOR, true>(tk, n_slab, s);
+    default: return 1;  // not instantiated (input width > 287): the caller runs the exact-f32 kernel
   }
 }
 
@@ -756,8 +894,12 @@ static int h2_dispatch(const TrainTask& tk, int n_slab, bool actor, hipStream_t 
   if (actor) {
     if (tk.action_f != nullptr) return 1;  // continuous head: exact-f32 kernel
     if (tk.no <= 8) return dispatch_s1<8, true>(tk, n_slab, s);
+#ifndef MAVA_FAST_BUILD
     if (tk.no <= 16) return dispatch_s1<16, true>(tk, n_slab, s);
     return dispatch_s1<32, true>(tk, n_slab, s);
+#else
+    return 1;
+#endif
   }
   return dispatch_s1<1, false>(tk, n_slab, s);
 }

@@ -7,18 +7,23 @@ from mava_amd import ops
 from mava_amd._lib import lib
 
 dev = torch.device("cuda", 0)
+MODE = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f16x2") else 0
 TE, A, O, nA = 128 * 4096, 4, 66, 5
 Rb = TE // 2
 rng = np.random.default_rng(0)
 names = ["P1 layer1", "P2 layer2+head", "P3 loss+dz2", "P4 dh1+sweeps", "P4b dz1 write", "P5a gW2", "P5b gW1", "barrier E",
          "commit+F", "loop top", "P2a prefetch issue", "P2b mfma loop", "P1a mfma loop", "barrier A", "x issue", "row issue"]
 # note: with sub-stamps, "P1 layer1" = epilogue after P1a, "P2 layer2+head" = head part after P2b
+if MODE == 1:  # phases of ppo_train_h2.hip
+    names = ["P1 mfma", "P1 relu+image", "gather issue", "barrier A", "P2 mfma", "P2 image+head", "barrier B", "P3 loss",
+             "B2+dz2+image", "barrier C", "P4 mfma+dz1+commit", "gW3+gW2", "barrier D", "gW1", "loop top", "-"]
 l = lib()
+l.mava_ppo_set_matmul_mode(MODE)
 l.mava_debug_set_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(64, dtype=torch.int64, device=dev)
 l.mava_debug_set_stamps(stamps.data_ptr())
 perm = torch.randperm(TE, device=dev).to(torch.int32)
-for which in ("critic", "actor"):
+for which in (("actor",) if MODE == 1 else ("critic", "actor")):
     if which == "critic":
         din = A * O
         params = torch.randn(ops.mlp_param_count(din, 1), device=dev) * 0.05

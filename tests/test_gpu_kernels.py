@@ -364,8 +364,8 @@ def test_train_kernels_full_launch_shape(dev, matmul_mode):
     with tools/debug_fullshape.py: identical errors for the exact-f32 and the f16x2 kernel, any slab count, any row
     order, while the losses agree to 1e-8 - a property of the comparison, not of the arithmetic).  Kinks: a hidden
     pre-activation within 5e-5 of zero (ReLU; ~4 % of the (t,e) indices are dropped), the PPO ratio within 1e-3 of
-    1 +- clip_eps and |value - old_value| within 1e-3 of clip_eps (the old log-probs / values are drawn outside
-    those bands)."""
+    1 +- clip_eps, |value - old_value| within 1e-3 of clip_eps, and targets midway between the value and its clipped
+    version (the old log-probs / old values / targets are drawn outside those bands)."""
     from mava_amd import ops
 
     TE, A, O, nA, Rb, n_slab = 524288, 4, 66, 5, 262144, 256
@@ -406,7 +406,12 @@ def test_train_kernels_full_launch_shape(dev, matmul_mode):
         dv = rng.standard_normal(r.size) * 0.2   # v - old_v
         dv = np.where(np.abs(np.abs(dv) - 0.2) < 1e-3, np.sign(dv) * 0.203, dv)
         old_v[r] = (v - dv).astype(np.float32)
-        tgt[r] = (v + rng.standard_normal(r.size)).astype(np.float32)
+        # ... and the max(l1, l2) kink of the clipped value loss: outside the clip range the gradient jumps where
+        # |v - tgt| == |v_clip - tgt|, i.e. where the target sits midway between v and v_clip
+        e1 = -rng.standard_normal(r.size)          # v - tgt
+        e2 = e1 - dv + np.clip(dv, -0.2, 0.2)      # v_clip - tgt
+        e1 = np.where((np.abs(dv) > 0.2) & (np.abs(np.abs(e1) - np.abs(e2)) < 2e-3), e1 + 5e-3, e1)
+        tgt[r] = (v - e1).astype(np.float32)
         keep.append(ii[~near])
         n_keep += int((~near).sum())
         if n_keep >= Rb:

@@ -23,7 +23,7 @@ l.mava_debug_set_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(64, dtype=torch.int64, device=dev)
 l.mava_debug_set_stamps(stamps.data_ptr())
 perm = torch.randperm(TE, device=dev).to(torch.int32)
-for which in (("actor",) if MODE == 1 else ("critic", "actor")):
+for which in ("critic", "actor"):
     if which == "critic":
         din = A * O
         params = torch.randn(ops.mlp_param_count(din, 1), device=dev) * 0.05

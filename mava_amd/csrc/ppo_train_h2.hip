@@ -163,13 +163,13 @@ H2Layout make_h2_layout(bool actor) {
   // partial logits (f32) live inside an image that is idle between barriers A and B2: dz2's (actor), dz1's (critic)
   L.yp = actor ? L.dz2 : L.dz1;
   L.agg = L.dy + (actor ? 2 * DY_PLANE : 0);
-  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[32] | misc[16]
+  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[32] | misc[16] | W3[128] (critic)
   L.small = (L.small + 15) & ~15;
-  L.end = L.small + (128 + 32 + 16) * 4;
+  L.end = L.small + (128 + 32 + 16 + 128) * 4;
   return L;
 }
 constexpr int W2_PLANE = 128 * IMG_ROW;
-constexpr int W1_RING = 6;  // WIDE: register ring depth in 16-input steps (S1 is padded to a multiple of it)
+constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 is padded to a multiple of it)
 
 // WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
 // lane (r, h) of wave w holds W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din zero.
@@ -188,11 +188,17 @@ __global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ 
   out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
 }
 
-template <int NO, int S1, bool ACTOR, bool WIDE, int XV>
-__global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2Layout L, const uint4* __restrict__ w1p) {
+// ROLE 0: one 4-wave group does everything (narrow inputs).  WIDE launches run 8 waves in two roles with disjoint register
+// sets (two waves per SIMD, 256 registers each): ROLE 1, the CHAIN group (waves 0-3: layers, loss, backward chain, dW2,
+// small gradients; W1 through a register ring), and ROLE 2, the LOADER group (waves 4-7: gathers and splits the x tiles,
+// owns the 9 x 16 accumulator registers of dW1).  Every role executes the same barrier sequence.
+template <int NO, int S1, bool ACTOR, bool WIDE, int XV, int ROLE>
+__device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, const uint4* __restrict__ w1p, u8* lds) {
   static_assert(!WIDE || S1 % W1_RING == 0, "WIDE: S1 must be a multiple of the W1 ring depth");
+  static_assert((ROLE == 0) == !WIDE, "roles 1 / 2 belong to WIDE launches");
+  constexpr bool CHAIN = ROLE != 2, LOADER = ROLE != 1;
+  constexpr int NTHR = WIDE ? 512 : 256;
   constexpr int KT1 = (S1 + 1) / 2;  // 32-input tiles of the layer-1 weight gradient
-  extern __shared__ __attribute__((aligned(16))) u8 lds[];
   u8* const H1I = lds + L.h1;
   u8* const DZ2I = lds + L.dz2;
   u8* const DZ1I = lds + L.dz1;
@@ -204,9 +210,10 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   float* const B2s = reinterpret_cast<float*>(lds + L.small);
   float* const B3s = B2s + 128;
   float* const misc = B3s + 32;
+  float* const W3s = misc + 16;  // critic: the 128 head weights (read per tile: head on the VALU, dz2 = W3[f] * dy)
   const int xs_row = L.xs_row, xs_plane = L.xs_plane;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // thread of its 4-wave group
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, r = lane & 31;
   const int srow = tid >> 3, l8 = tid & 7;  // staging role: row srow of the tile, 8 threads per row
   const int din = tk.din, no = tk.no;
@@ -216,19 +223,20 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   constexpr int NR = NPC * XV;
 
   // ---------------------------------------------------------------- prologue: LDS images, small vectors
-  for (int i = tid * 16; i < L.end; i += 256 * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x * 16; i < L.end; i += NTHR * 16) *reinterpret_cast<uint4*>(lds + i) = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const float* const P = tk.params;
   const int oW2 = mlp_off_w2(din), oW3 = mlp_off_w3(din);
-  {
+  if (CHAIN) {
     if (tid < 128) B2s[tid] = P[mlp_off_b2(din) + tid];
     if (tid < no) B3s[tid] = P[mlp_off_b3(din, no) + tid];
+    if (!ACTOR && tid < 128) W3s[tid] = P[oW3 + tid];
     // the ones column of the x buffers: "row din" of W1 in the flat parameter vector is b1
     if (tid < (WIDE ? 32 : 64)) {
       const int b = tid >> 5, row = tid & 31;
       *reinterpret_cast<_Float16*>(lds + L.xs + b * 2 * xs_plane + row * xs_row + 2 * din) = (_Float16)1.0f;
     }
-    // W2 image: thread t converts rows k = t / 2, t / 2 + ... : 16384 elements, 64 per thread, 4 at a time
+    // W2 image: 16384 elements, 64 per thread, 4 at a time
     for (int i = tid; i < 128 * 32; i += 256) {
       const int k = i >> 5, c4 = i & 31;
       const float4 v = *reinterpret_cast<const float4*>(P + oW2 + k * MLP_H + 4 * c4);
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   // ---------------------------------------------------------------- weight fragments kept in registers
   // layer 1 (A operand): W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din is zero.  Narrow inputs: all S1
   // steps resident; WIDE: a ring of W1_RING steps fed from the pre-split global copy.
-  constexpr int NW1 = WIDE ? W1_RING : S1;
+  constexpr int NW1 = !CHAIN ? 1 : (WIDE ? W1_RING : S1);
   Frag W1f[NW1];
   const uint4* const w1p_lane = w1p + 2 * (w * 64 + lane);  // + 2 * 256 * s
   auto w1_fetch = [&](int s) -> Frag {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     return f;
   };
 #pragma unroll
-  for (int s = 0; s < NW1; ++s) {
+  for (int s = 0; s < (CHAIN ? NW1 : 0); ++s) {
     if (WIDE) {
       W1f[s] = w1_fetch(s);
     } else {
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   // lane half h in k-step s is feature 32w + 16s + 8(e>>2) + 4h + (e&3)
   Frag W3h[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < ((CHAIN && ACTOR) ? 2 : 0); ++s) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -292,8 +300,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     W3h[s] = split8(v);
   }
   Frag W3d;  // actor: A of dz2 = W3 . dy: W3[f = 32w + r][o = 8h + e]
-  float w3v[ACTOR ? 1 : 16];  // critic: W3[f] of the lane's 16 accumulator features (dz2 = W3[f] * dy on the VALU)
-  if (ACTOR) {
+  if (CHAIN && ACTOR) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -301,18 +308,15 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       v[e] = (o < no) ? P[oW3 + (32 * w + r) * no + o] * W3_SCALE : 0.0f;
     }
     W3d = split8(v);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) w3v[q] = P[oW3 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
   }
   __syncthreads();
   const float adv_mean = ACTOR ? misc[0] : 0.0f;
   const float adv_rstd = ACTOR ? misc[1] : 0.0f;
 
   // persistent accumulators (R x gradient units): wave w owns output columns [32w, 32w+32) of dW1 and dW2
-  f32x16 gW1[KT1], gW2[4], gW3;
+  f32x16 gW1[LOADER ? KT1 : 1], gW2[4], gW3;
 #pragma unroll
-  for (int t = 0; t < KT1; ++t)
+  for (int t = 0; t < (LOADER ? KT1 : 1); ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) gW1[t][q] = 0.0f;
 #pragma unroll
@@ -439,24 +443,36 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   int32_t ps_next = 0, pl_next[NP] = {};
   uint32_t as_next = 0, al_next[NP] = {};
   if (it < ntiles) {
-    cursor_gather(cs, ps_next, as_next);
-    stage_issue(stage_row(ps_next, as_next), xr);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      cursor_gather(cl[q], pl_next[q], al_next[q]);
-      load_row((long)((uint32_t)pl_next[q] * Au + al_next[q]), r_act[q], r_f0[q], r_f1[q], r_m[q]);
-    }
-    stage_commit(0, xr);
-    cursor_advance(cs);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
-    if (it + gridDim.x < ntiles) {
+    if (LOADER) {
       cursor_gather(cs, ps_next, as_next);
+      stage_issue(stage_row(ps_next, as_next), xr);
+    }
+    if (CHAIN) {
 #pragma unroll
-      for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+      for (int q = 0; q < NP; ++q) {
+        cursor_gather(cl[q], pl_next[q], al_next[q]);
+        load_row((long)((uint32_t)pl_next[q] * Au + al_next[q]), r_act[q], r_f0[q], r_f1[q], r_m[q]);
+      }
+    }
+    if (LOADER) {
+      stage_commit(0, xr);
       cursor_advance(cs);
+    }
+    if (CHAIN) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+    }
+    if (it + gridDim.x < ntiles) {
+      if (LOADER) {
+        cursor_gather(cs, ps_next, as_next);
+        cursor_advance(cs);
+      }
+      if (CHAIN) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+      }
     }
   }
   __syncthreads();
@@ -477,31 +493,39 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
     const bool valid = (it * 32 + r) < R;
     const long itn = it + gridDim.x;
     const bool have_next = itn < ntiles;
-    uint32_t xrow_next = stage_row(ps_next, as_next);
+    uint32_t xrow_next = LOADER ? stage_row(ps_next, as_next) : 0u;
     uint32_t fr_next[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) fr_next[q] = (uint32_t)pl_next[q] * Au + al_next[q];
-    asm volatile("" : "+v"(xrow_next));
+    for (int q = 0; q < NP; ++q) fr_next[q] = CHAIN ? ((uint32_t)pl_next[q] * Au + al_next[q]) : 0u;
+    if (LOADER) asm volatile("" : "+v"(xrow_next));
+    if (CHAIN) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(fr_next[q]));
+      for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(fr_next[q]));
+    }
     const u8* const XSI = lds + L.xs + buf * 2 * xs_plane;
 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x16 acc;
+    uint32_t relu1 = 0;
+    if constexpr (CHAIN) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    // operand reads run ONE step ahead of their MFMAs (explicit double buffer + scheduling fence: without it the
+    // compiler hoists every read of the unrolled loop and spills)
+    Frag xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h);
 #pragma unroll
     for (int s = 0; s < S1; ++s) {
-      const Frag b = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * s);
+      const Frag b = xb;
+      if (s + 1 < S1) xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * (s + 1));
       acc = mfma3(W1f[s % NW1], b, acc);
       if (WIDE) {
         // refill the slot consumed one step ago with step s - 1 + W1_RING (wrapping to the head steps of the next tile)
         if (s >= 1) W1f[(s - 1) % NW1] = w1_fetch((s - 1 + W1_RING) % S1);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (WIDE) W1f[(S1 - 1) % NW1] = w1_fetch((S1 - 1 + W1_RING) % S1);
     STAMP(0);
-    uint32_t relu1 = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       acc[q] = fmaxf(acc[q], 0.0f);
@@ -511,19 +535,26 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       half4 ph[4], pl[4];
       write_image(H1I, r, 32 * w + 4 * h, acc, ph, pl);
     }
+    }  // CHAIN
     STAMP(1);
     // next tile's gathers: issued after P1 (their latency hides under P2..P4)
     if (have_next) {
-      stage_issue(xrow_next, xr);
+      if (LOADER) stage_issue(xrow_next, xr);
+      if (CHAIN) {
 #pragma unroll
-      for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+        for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+      }
       if (itn + gridDim.x < ntiles) {
-        cursor_gather(cs, ps_next, as_next);
+        if (LOADER) {
+          cursor_gather(cs, ps_next, as_next);
+          cursor_advance(cs);
+        }
+        if (CHAIN) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
-        cursor_advance(cs);
+          for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+          for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+        }
       }
     }
     STAMP(2);
@@ -532,36 +563,41 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
 
     // ---------------------------------------------------------------- P2: z2 = b2 + W2^T h1^T ; head partial logits
     f32x16 h2;
+    uint32_t relu2 = 0;
+    if constexpr (CHAIN) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
+    {
+      Frag an = read_tr_frag(W2I + trI + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
+      Frag bn = read_row_frag(H1I, IMG_PLANE, rowB);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const Frag a = read_tr_frag(W2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
-      const Frag b = read_row_frag(H1I, IMG_PLANE, rowB + 32 * s);
-      h2 = mfma3(a, b, h2);
+      for (int s = 0; s < 8; ++s) {
+        const Frag a = an, b = bn;
+        if (s + 1 < 8) {
+          an = read_tr_frag(W2I + trI + 16 * (s + 1) * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
+          bn = read_row_frag(H1I, IMG_PLANE, rowB + 32 * (s + 1));
+        }
+        h2 = mfma3(a, b, h2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     STAMP(4);
-    uint32_t relu2 = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       h2[q] = fmaxf(h2[q], 0.0f);
       relu2 |= (h2[q] > 0.0f) ? (1u << q) : 0u;
     }
-    {
+    if (!ACTOR) {
+      // critic head on the VALU: this lane's 16 features of row r, the two lane halves added by one exchange; the four
+      // waves' partial values meet in YP
+      float part = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) part = fmaf(h2[q], W3s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h], part);
+      part += __shfl_xor(part, 32, 64);
+      if (h == 0) YP[(w * 32 + r) * (NO + 1)] = part;
+    } else {
       half4 ph[4], pl[4];
-      if (ACTOR) {
-        write_image(H2I, r, 32 * w + 4 * h, h2, ph, pl);
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            _Float16 a, b;
-            split1(h2[4 * g + e], a, b);
-            ph[g][e] = a;
-            pl[g][e] = b;
-          }
-      }
+      write_image(H2I, r, 32 * w + 4 * h, h2, ph, pl);
       f32x16 yacc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) yacc[q] = 0.0f;
@@ -573,24 +609,23 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         yacc = mfma3(W3h[s], b, yacc);
       }
       // partial logits of this wave: register q of lane (row r, half h) is output (q&3) + 8(q>>2) + 4h
-      if (ACTOR) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
-          if ((q & 3) + 8 * (q >> 2) < NO) {
-            if (o < NO) YP[(w * 32 + r) * (NO + 1) + o] = yacc[q] * W3_UNSCALE;
-          }
+      for (int q = 0; q < 16; ++q) {
+        const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+        if ((q & 3) + 8 * (q >> 2) < NO) {
+          if (o < NO) YP[(w * 32 + r) * (NO + 1) + o] = yacc[q] * W3_UNSCALE;
         }
-      } else {
-        if (h == 0) YP[(w * 32 + r) * (NO + 1)] = yacc[0] * W3_UNSCALE;
       }
     }
+    }  // CHAIN
     STAMP(5);
     __syncthreads();  // B: partial logits (and the h2 image) complete
     STAMP(6);
 
     // ---------------------------------------------------------------- P3: loss, d loss / d logits (x R), dW3, dz2
     f32x16 dz;
+    float dy0 = 0.0f;  // critic: d loss / d value of row r (x R)
+    if constexpr (CHAIN) {
     if (ACTOR) {
       const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
 #pragma unroll
@@ -635,8 +670,38 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
           loss_b += ent * invR;
         }
       }
-      STAMP(7);
-      __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
+    } else {
+      const float* yp = YP + r * (NO + 1);
+      const float v = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[0];
+      const float ov = r_f0[0], tg = r_f1[0];
+      const float diff = v - ov;
+      const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+      const float e1 = v - tg, e2 = vclip - tg;
+      const float l1 = e1 * e1, l2 = e2 * e2;
+      const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+      const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+      const float g2 = inside ? (1.0f - g1) : 0.0f;
+      dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2)) : 0.0f;  // x R
+      if (tk.agg > 1) {
+        // this lane evaluated agent `slot` of row r: the value is shared by the row's agents, so the backward pass
+        // runs once on the sum of their loss gradients
+        const bool mine = valid && slot < tk.agg;
+        dy0 = mine ? dy0 : 0.0f;
+        if (mine) {
+          loss_a += 0.5f * fmaxf(l1, l2) * invR;
+          ab3 += dy0;
+        }
+        AGG[slot * 33 + r] = dy0;
+      } else if (valid && w == 0 && h == 0) {
+        loss_a += 0.5f * fmaxf(l1, l2) * invR;
+        ab3 += dy0;
+      }
+    }
+    }  // CHAIN
+    STAMP(7);
+    __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
+    if constexpr (CHAIN) {
+    if (ACTOR) {
       // gW3^T[o][f = 32w + r] += sum_rows dy[row][o] h2[row][f]   (outputs >= NO of the dy image are zero)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -657,38 +722,15 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
         ab2[q] += dz[q];
       }
     } else {
-      const float* yp = YP + r * (NO + 1);
-      const float v = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[0];
-      const float ov = r_f0[0], tg = r_f1[0];
-      const float diff = v - ov;
-      const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
-      const float e1 = v - tg, e2 = vclip - tg;
-      const float l1 = e1 * e1, l2 = e2 * e2;
-      const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
-      const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-      const float g2 = inside ? (1.0f - g1) : 0.0f;
-      float dy0 = valid ? (tk.vf_coef * (g1 * e1 + g2 * e2)) : 0.0f;  // x R
       if (tk.agg > 1) {
-        const bool mine = valid && slot < tk.agg;
-        dy0 = mine ? dy0 : 0.0f;
-        if (mine) {
-          loss_a += 0.5f * fmaxf(l1, l2) * invR;
-          ab3 += dy0;
-        }
-        AGG[slot * 33 + r] = dy0;
-        STAMP(7);
-        __syncthreads();  // B2
         float sum = 0.0f;
 #pragma unroll
         for (int a = 0; a < 8; ++a) sum += AGG[a * 33 + r];  // fixed order: identical in every lane
         dy0 = sum;
-      } else if (valid && w == 0 && h == 0) {
-        loss_a += 0.5f * fmaxf(l1, l2) * invR;
-        ab3 += dy0;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        dz[q] = ((relu2 >> q) & 1u) ? (w3v[q] * dy0) : 0.0f;
+        dz[q] = ((relu2 >> q) & 1u) ? (W3s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] * dy0) : 0.0f;
         ab2[q] += dz[q];
         aW3r[q] = fmaf(h2[q], dy0, aW3r[q]);
       }
@@ -697,66 +739,87 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
       half4 ph[4], pl[4];
       write_image(DZ2I, r, 32 * w + 4 * h, dz, ph, pl);
     }
+    }  // CHAIN
     STAMP(8);
     __syncthreads();  // C: dz2 image complete; the h2 image is free (it becomes dz1's)
     STAMP(9);
 
-    // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW2
+    // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW2 ; dW1
+    auto do_gw2 = [&]() {
+      // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      for (int s = 0; s < 2; ++s) {
+        const Frag b = read_tr_frag(DZ2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const Frag a = read_row_frag(W2I, W2_PLANE, w2row + 32 * s);
-      const Frag b = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * s);
-      acc = mfma3(a, b, acc);
-    }
+        for (int t = 0; t < 4; ++t) {
+          const Frag a = read_tr_frag(H1I + trI + 16 * s * IMG_ROW + 2 * (32 * t), IMG_PLANE, IMG_ROW);
+          gW2[t] = mfma3(a, b, gW2[t]);
+          if (t & 1) __builtin_amdgcn_sched_barrier(0);  // at most two tiles' operand reads in flight
+        }
+      }
+    };
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
-    {
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      Frag an = read_row_frag(W2I, W2_PLANE, w2row);
+      Frag bn = read_row_frag(DZ2I, IMG_PLANE, rowB);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const Frag a = an, b = bn;
+        if (s + 1 < 8) {
+          an = read_row_frag(W2I, W2_PLANE, w2row + 32 * (s + 1));
+          bn = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * (s + 1));
+        }
+        acc = mfma3(a, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
       half4 ph[4], pl[4];
       write_image(DZ1I, r, 32 * w + 4 * h, acc, ph, pl);
     }
-    // narrow inputs: the next tile's x rows have arrived long ago - split + store them into the other buffer (read
-    // from barrier D on)
-    if (!WIDE && have_next) stage_commit(buf ^ 1, xr);
-    STAMP(10);
-    // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const Frag b = read_tr_frag(DZ2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const Frag a = read_tr_frag(H1I + trI + 16 * s * IMG_ROW + 2 * (32 * t), IMG_PLANE, IMG_ROW);
-        gW2[t] = mfma3(a, b, gW2[t]);
-      }
+    if constexpr (!WIDE) {
+      // narrow inputs: the next tile's x rows have arrived long ago - split + store them into the other buffer (read
+      // from barrier D on)
+      if (have_next) stage_commit(buf ^ 1, xr);
     }
+    STAMP(10);
+    if constexpr (!WIDE) do_gw2();
     STAMP(11);
-    __syncthreads();  // D: dz1 image (and the next x tile) complete
+    __syncthreads();  // D: dz1 image (narrow inputs: and the next x tile) complete
     STAMP(12);
-    // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
+    if constexpr (WIDE && CHAIN) do_gw2();  // beside the loader group's dW1 product
+    if constexpr (LOADER) {
+      // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const Frag b = read_tr_frag(DZ1I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+      for (int s = 0; s < 2; ++s) {
+        const Frag b = read_tr_frag(DZ1I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
 #pragma unroll
-      for (int t = 0; t < KT1; ++t) {
-        const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);
-        gW1[t] = mfma3(a, b, gW1[t]);
+        for (int t = 0; t < KT1; ++t) {
+          const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);
+          gW1[t] = mfma3(a, b, gW1[t]);
+          if (t & 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     STAMP(13);
-    if (WIDE) {
+    if constexpr (WIDE) {
       __syncthreads();  // E: every reader of the (single) x tile is done
-      if (have_next) stage_commit(0, xr);
+      if constexpr (LOADER) {
+        if (have_next) stage_commit(0, xr);
+      }
       __syncthreads();  // F: next x tile visible
     }
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) { r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; r_m[q] = n_m[q]; }
+      for (int q = 0; q < NP; ++q) { r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; r_m[q] = n_m[q]; }
+    }
     // narrow inputs: no barrier here - the next tile's P1 writes the h1 image, whose last readers (gW2) sit before
     // barrier D, and reads the other x buffer, complete since D; every other image is rewritten only behind barriers A..C
   }
 #ifdef MAVA_STAMPS
   if (tk.stamps != nullptr && blockIdx.x == 0 && lane == 0) {
-    for (int i = 0; i < 16; ++i) tk.stamps[w * 16 + i] = st_acc[i];
+    for (int i = 0; i < 16; ++i) tk.stamps[((ROLE == 2 ? 4 : 0) + w) * 16 + i] = st_acc[i];
   }
 #endif
 
@@ -765,26 +828,32 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
   const int oB2 = mlp_off_b2(din), oB3 = mlp_off_b3(din, no);
   const int Pn = mlp_param_count(din, no);
+  if constexpr (LOADER) {
 #pragma unroll
-  for (int t = 0; t < KT1; ++t)
+    for (int t = 0; t < KT1; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = mlp_feat(t, q, h);
+        if (k <= din) slab[k * MLP_H + 32 * w + r] = gW1[t][q] * invR;  // row din = db1
+      }
+  }
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slab[oW2 + mlp_feat(t, q, h) * MLP_H + 32 * w + r] = gW2[t][q] * invR;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int k = mlp_feat(t, q, h);
-      if (k <= din) slab[k * MLP_H + 32 * w + r] = gW1[t][q] * invR;  // row din = db1
+      float v = ab2[q];
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (r == 0) slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
     }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) slab[oW2 + mlp_feat(t, q, h) * MLP_H + 32 * w + r] = gW2[t][q] * invR;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    float v = ab2[q];
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    if (r == 0) slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
   }
   float* red = reinterpret_cast<float*>(lds + L.h1);  // epilogue scratch (the tile loop is over)
-  if (ACTOR) {
+  if constexpr (!CHAIN) {
+    __syncthreads();
+  } else if (ACTOR) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -828,6 +897,21 @@ __global__ __launch_bounds__(256, 1) void ppo_train_h2_kernel(TrainTask tk, H2La
   }
 }
 
+template <int NO, int S1, bool ACTOR, bool WIDE, int XV>
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 2 : 1) void ppo_train_h2_kernel(TrainTask tk, H2Layout L,
+                                                                                     const uint4* __restrict__ w1p) {
+  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+  if constexpr (WIDE) {
+    if (threadIdx.x < 256) {
+      h2_body<NO, S1, ACTOR, WIDE, XV, 1>(tk, L, w1p, lds);
+    } else {
+      h2_body<NO, S1, ACTOR, WIDE, XV, 2>(tk, L, w1p, lds);
+    }
+  } else {
+    h2_body<NO, S1, ACTOR, WIDE, XV, 0>(tk, L, w1p, lds);
+  }
+}
+
 // WIDE launches: one pre-split copy of W1 per network kind, allocated on first use and kept for the process
 // (18 steps x 256 lanes x 32 bytes = 147 KB); filled by pack_w1_kernel on the launch stream ahead of every launch.
 uint4* g_w1p[2] = {nullptr, nullptr};
@@ -850,7 +934,8 @@ int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
     MAVA_LAUNCH_CHECK();
     w1p = buf;
   }
-  hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR, WIDE, XV>), dim3(n_slab), dim3(256), L.end, s, tk, L, w1p);
+  hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR, WIDE, XV>), dim3(n_slab), dim3(WIDE ? 512 : 256), L.end, s, tk, L,
+                     w1p);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

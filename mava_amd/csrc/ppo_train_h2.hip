@@ -68,6 +68,29 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)(v - (float)hi);
 }
+// WEIGHT split with error diffusion along the product's summation index: what the two f16 terms of one weight fail
+// to represent (|.| <= 2^-22 |w|) is carried into the low term of the NEXT weight of the same output feature, so the
+// representation errors of a column sum to one final carry instead of adding up.  Why: a weight's representation
+// error is the same for every batch row - with non-negative (post-ReLU) inputs it shifts an output feature
+// coherently in all rows, and in a gradient that cancels to 1/sqrt(rows) of its terms (the value loss at 10^6 rows)
+// that shift was the one visible difference to exact f32 (2.6e-4 of the gradient's rms on 3 of 50 561 entries).
+__device__ __forceinline__ void split1_carry(float v, float& carry, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  const float rr = (v - (float)hi) + carry;  // exact residual of hi, plus what earlier weights could not represent
+  lo = (_Float16)rr;
+  carry = rr - (float)lo;
+}
+__device__ __forceinline__ Frag split8_carry(const float (&v)[8], float& carry) {
+  Frag f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 a, b;
+    split1_carry(v[i], carry, a, b);
+    f.hi[i] = a;
+    f.lo[i] = b;
+  }
+  return f;
+}
 __device__ __forceinline__ Frag split8(const float (&v)[8]) {
   Frag f;
 #pragma unroll
@@ -174,18 +197,20 @@ constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 i
 // WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
 // lane (r, h) of wave w holds W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din zero.
 __global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, int steps, uint4* __restrict__ out) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= steps * 256) return;
-  const int s = gid >> 8, w = (gid >> 6) & 3, lane = gid & 63, r = lane & 31, h = lane >> 5;
-  float v[8];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  float carry = 0.0f;  // error diffusion along k over this lane's inputs of feature 32w + r (split1_carry)
+  for (int s = 0; s < steps; ++s) {
+    float v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = 16 * s + 8 * h + e;
-    v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * h + e;
+      v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+    }
+    const Frag f = split8_carry(v, carry);
+    const int gid = s * 256 + threadIdx.x;
+    out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
+    out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
   }
-  const Frag f = split8(v);
-  out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
-  out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
 }
 
 // ROLE 0: one 4-wave group does everything (narrow inputs).  WIDE launches run 8 waves in two roles with disjoint register
@@ -236,18 +261,18 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       const int b = tid >> 5, row = tid & 31;
       *reinterpret_cast<_Float16*>(lds + L.xs + b * 2 * xs_plane + row * xs_row + 2 * din) = (_Float16)1.0f;
     }
-    // W2 image: 16384 elements, 64 per thread, 4 at a time
-    for (int i = tid; i < 128 * 32; i += 256) {
-      const int k = i >> 5, c4 = i & 31;
-      const float4 v = *reinterpret_cast<const float4*>(P + oW2 + k * MLP_H + 4 * c4);
-      half4 a, b;
-      _Float16 x0, x1;
-      split1(v.x, x0, x1); a[0] = x0; b[0] = x1;
-      split1(v.y, x0, x1); a[1] = x0; b[1] = x1;
-      split1(v.z, x0, x1); a[2] = x0; b[2] = x1;
-      split1(v.w, x0, x1); a[3] = x0; b[3] = x1;
-      *reinterpret_cast<half4*>(W2I + k * IMG_ROW + 8 * c4) = a;
-      *reinterpret_cast<half4*>(W2I + W2_PLANE + k * IMG_ROW + 8 * c4) = b;
+    // W2 image: thread = (output feature n, half of the k range); sequential over k with the error-diffusion carry
+    // of split1_carry (layer 2 sums over k: the representation errors of a column then sum to two final carries)
+    {
+      const int n = tid & 127, k0 = 64 * (tid >> 7);
+      float carry = 0.0f;
+#pragma unroll 8
+      for (int k = k0; k < k0 + 64; ++k) {
+        _Float16 x0, x1;
+        split1_carry(P[oW2 + k * MLP_H + n], carry, x0, x1);
+        *reinterpret_cast<_Float16*>(W2I + k * IMG_ROW + 2 * n) = x0;
+        *reinterpret_cast<_Float16*>(W2I + W2_PLANE + k * IMG_ROW + 2 * n) = x1;
+      }
     }
     if (ACTOR && tid == 0) {
       // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
@@ -272,6 +297,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     f.lo = __builtin_bit_cast(half8, w1p_lane[512 * s + 1]);
     return f;
   };
+  float w1_carry = 0.0f;
 #pragma unroll
   for (int s = 0; s < (CHAIN ? NW1 : 0); ++s) {
     if (WIDE) {
@@ -283,7 +309,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
         const int k = 16 * s + 8 * h + e;
         v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
       }
-      W1f[s] = split8(v);
+      W1f[s] = split8_carry(v, w1_carry);
     }
   }
   // head: logits^T[o = r][row] += sum over the wave's 32 features, B = the layer-2 accumulator itself: element e of
@@ -930,7 +956,7 @@ int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
   if (WIDE) {
     uint4*& buf = g_w1p[ACTOR ? 0 : 1];
     if (buf == nullptr) MAVA_HIP_CHECK(hipMalloc((void**)&buf, (size_t)18 * 256 * 32));
-    hipLaunchKernelGGL(pack_w1_kernel, dim3(S1), dim3(256), 0, s, tk.params, tk.din, S1, buf);
+    hipLaunchKernelGGL(pack_w1_kernel, dim3(1), dim3(256), 0, s, tk.params, tk.din, S1, buf);
     MAVA_LAUNCH_CHECK();
     w1p = buf;
   }

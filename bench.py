@@ -117,7 +117,7 @@ def main() -> None:
     ap.add_argument("--action-head", default="discrete", choices=["discrete", "continuous"],
                     help="continuous: network.action_head=ContinuousActionHead on a MaBrax-shaped synthetic env "
                          "(--agents, --obs-dim, --action-dim; SURVEY 8f N4) - a secondary workload, not the headline metric")
-    ap.add_argument("--matmul", default="f32", choices=["f32", "f16x2"],
+    ap.add_argument("--matmul", default="f16x2", choices=["f32", "f16x2"],
                     help="arithmetic of the fused PPO gradient kernels: exact-f32 MFMA, or split-f16 operands (3 f16 MFMAs per "
                          "product, f32 accumulate; mava_ppo_set_matmul_mode)")
     ap.add_argument("--agents", type=int, default=4)
@@ -169,6 +169,7 @@ def main() -> None:
     # run_experiment does (mava/systems/ppo/ff_mappo.py:496-504: wall time of learn + block_until_ready)
     cfg.system.num_updates_per_eval = max(args.steps, 1)
     cfg.system.num_updates = max(args.steps + args.warmup, 1)
+    cfg.system.matmul_mode = args.matmul
     central = args.system.endswith("mappo")
     mod = {"ff_mappo": ff_mappo, "ff_ippo": ff_ippo, "rec_mappo": rec_mappo, "rec_ippo": rec_ippo}[args.system]
     env, _ = envs.make(cfg, add_global_state=central, device=dev)
@@ -188,9 +189,6 @@ def main() -> None:
         from mava_amd._lib import lib as _mava_lib
 
         _mava_lib().mava_ppo_set_critic_aggregation(0)
-    from mava_amd._lib import lib as _mava_lib2
-
-    _mava_lib2().mava_ppo_set_matmul_mode(1 if args.matmul == "f16x2" else 0)
     log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc} matmul={args.matmul}")
     for i in range(args.warmup):
         L.update(0)

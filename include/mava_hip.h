@@ -181,6 +181,27 @@ int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int 
                           float* reward, uint8_t* done, float* info_return, int32_t* info_length,
                           uint8_t* info_terminal, const int32_t* action, int reward_mode, mava_stream_t s);
 
+/* ---- fused rollout: the whole `lax.scan(_env_step, length=T)` of mava/systems/ppo/ff_mappo.py:76-106 for one
+ *      update-batch replica on the synthetic RWARE-shaped environment, plus the bootstrap value of :109-110, in ONE
+ *      launch (mava_amd/csrc/rollout_h2.hip): every workgroup owns 64 / A environments for all T steps (environments
+ *      are independent, the parameters fixed), weights register-resident, observations handed from the env phase to
+ *      the next acting step through LDS.  Same Philox streams as mava_policy_step_f32 (seed policy_seed, counter
+ *      (row_offset + row, t0 + t, ., "POLI")) and mava_synth_rware_step (seed env_seed, step t0 + t + 1): bit-identical
+ *      observations / masks / rewards / dones / metrics; networks in split-f16 arithmetic (see mava_ppo_set_matmul_mode).
+ *      critic_shared 1: centralised critic on global_state (T+1, E, A*O), one value per env broadcast to its agents;
+ *      0: decentralised critic on agents_view (global_state unused).  Slot 0 of agents_view / global_state /
+ *      action_mask must hold the current observation; slots 1..T are written, the env state is advanced in place.
+ *      Returns 0, a negative error, or 1 when the shape is not instantiated (the caller then runs mava_policy_step_f32
+ *      + mava_synth_rware_step per step): needs 64 % A == 0, n_actions <= 8, the RWARE-style global state. */
+int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* critic_params, int critic_shared,
+                        int E, int A, int O, int T, int time_limit, uint64_t policy_seed, uint64_t env_seed,
+                        uint32_t t0, uint32_t row_offset, uint32_t env_offset, int reward_mode,
+                        int32_t* step_count, float* run_return, int32_t* run_length, float* ep_return,
+                        int32_t* ep_length, float* agents_view, float* global_state, uint8_t* action_mask,
+                        int32_t* obs_step_count, int32_t* action, float* value, float* reward, float* log_prob,
+                        uint8_t* done, float* last_val, float* info_return, int32_t* info_length,
+                        uint8_t* info_terminal, mava_stream_t s);
+
 /* ---- recurrent systems (rec_ippo / rec_mappo): mava/networks.py:238-331 (ScannedRNN GRU with
  *      reset-on-done, RecurrentActor, RecurrentValueNet), mava/systems/ppo/rec_mappo.py:91-149,
  *      :210-266, :334-365.  Internal activations use the "T32" tile layout: element (row, f) of a

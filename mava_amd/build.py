@@ -23,6 +23,7 @@ HIP_SOURCES = [
     "mlp_coop.hip",
     "ppo_train.hip",
     "ppo_train_h2.hip",
+    "rollout_h2.hip",
     "synth_rware.hip",
     "rec_dense.hip",
     "rec_gru.hip",

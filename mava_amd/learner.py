@@ -155,6 +155,20 @@ class FFLearner:
         self._graph_seen: set = set()
         self.seed = int(s.seed)
         self.timers: Optional[Dict[str, list]] = None  # bench.py: name -> [(start_event, end_event)]
+        # Arithmetic of the matrix products (not a Mava key): "f16x2" (default) = every operand split into two f16
+        # terms, three f16 MFMAs per product with f32 accumulation (ppo_train_h2.hip, rollout_h2.hip: ~22 mantissa bits
+        # per operand, the 1e-4 gradient parity tests run on it) for the shapes those kernels instantiate; "f32" = the
+        # exact-f32 MFMA kernels everywhere.  system.matmul_mode / MAVA_MATMUL select it.
+        self.matmul_mode = str(s.get("matmul_mode", None) or os.environ.get("MAVA_MATMUL", "f16x2"))
+        if self.matmul_mode not in ("f16x2", "f32"):
+            raise ValueError(f"system.matmul_mode must be 'f16x2' or 'f32', got {self.matmul_mode!r}")
+        ops.lib().mava_ppo_set_matmul_mode(1 if self.matmul_mode == "f16x2" else 0)
+        # the whole rollout in one launch (rollout_h2.hip) when the shape is instantiated; MAVA_FUSED_ROLLOUT=0 keeps
+        # the per-step kernels
+        self.fused_rollout = (self.matmul_mode == "f16x2" and not self.continuous
+                              and os.environ.get("MAVA_FUSED_ROLLOUT", "1") != "0"
+                              and int(getattr(env0, "synth_state_dim", 0)) == 0
+                              and (not centralised_critic or (env0.gs_tiles == 1 and env0.global_state_shared)))
 
     def _timed(self, name: str, fn, *args, **kwargs):
         """Run one kernel launch, optionally bracketed by HIP events on the launch stream."""
@@ -247,6 +261,9 @@ class FFLearner:
         The first call runs eagerly, the second is captured into a HIP graph, later ones replay it - the kernels
         read the moving step counter from step_dev, everything else they touch (incl. the metrics staging slots)
         is persistent, so the one graph serves every update index."""
+        if self.fused_rollout and self._rollout_fused(n):
+            self.t_global += self.T
+            return
         if not self.graph_rollout or self.timers is not None:
             self._rollout_body()
             self._bootstrap_and_gae()
@@ -272,6 +289,35 @@ class FFLearner:
             rep.info_length[n].copy_(rep.cur_length)
             rep.info_terminal[n].copy_(rep.cur_terminal)
         self.t_global += self.T
+
+    def _rollout_fused(self, n: int) -> bool:
+        """ff_mappo.py:76-110 + GAE: one launch per replica for all T acting + env steps and the bootstrap value
+        (mava_rollout_ff_f32), then the GAE kernel.  False when the library does not instantiate the shape."""
+        s = self.config.system
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        EA = self.E * self.A
+        for u, rep in enumerate(self.reps):
+            env = rep.env
+            ok = self._timed(
+                "rollout_fused", ops.rollout_ff, pa, pc, n_actions=self.nA, critic_shared=self.centralised, E=self.E,
+                A=self.A, O=env.raw_obs_dim, T=self.T, time_limit=env.time_limit, policy_seed=self.seed,
+                env_seed=env.seed, t0=self.t_global, row_offset=(self.rank * self.U + u) * EA, env_offset=env.env_offset,
+                reward_mode=1 if env.reward_mode == "match" else 0, env_state=rep.state, agents_view=rep.agents_view,
+                global_state=rep.global_state, action_mask=rep.action_mask, obs_step_count=rep.step_count,
+                action=rep.action, value=rep.value, reward=rep.reward, log_prob=rep.log_prob, done=rep.done,
+                last_val=rep.last_val, info_return=rep.info_return[n], info_length=rep.info_length[n],
+                info_terminal=rep.info_terminal[n])
+            if not ok:
+                assert u == 0
+                self.fused_rollout = False
+                return False
+            rep.last_reward.copy_(rep.reward[self.T - 1])
+            rep.last_done.copy_(rep.done[self.T - 1])
+            self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
+                        rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
+                        out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
+        self.step_dev.add_(self.T)
+        return True
 
     def _rollout_body(self) -> None:
         """ff_mappo.py:76-106: T acting steps, recording the time-major trajectory in place."""

@@ -384,3 +384,47 @@ def slab_reduce2(slab: torch.Tensor, n_main: int, out_main: torch.Tensor, n_tail
                                     int(accumulate), stream_ptr()),
         "mava_slab_reduce2_f32",
     )
+
+
+def rollout_ff(actor_params, critic_params, *, n_actions: int, critic_shared: bool, E: int, A: int, O: int, T: int,
+               time_limit: int, policy_seed: int, env_seed: int, t0: int, row_offset: int, env_offset: int,
+               reward_mode: int, env_state, agents_view, global_state, action_mask, obs_step_count, action, value,
+               reward, log_prob, done, last_val, info_return, info_length, info_terminal) -> bool:
+    """The whole rollout of one replica in one launch (mava_rollout_ff_f32).  Returns False when the library does not
+    instantiate the shape - the caller then steps policy_step / env.step_into per time step."""
+    W = A + O
+    _req(actor_params, torch.float32, "actor_params")
+    _req(critic_params, torch.float32, "critic_params")
+    if actor_params.numel() != mlp_param_count(W, n_actions):
+        raise ValueError("actor_params: wrong size")
+    if critic_params.numel() != mlp_param_count(A * O if critic_shared else W, 1):
+        raise ValueError("critic_params: wrong size")
+    _req(agents_view, torch.float32, "agents_view", (T + 1, E, A, W))
+    if critic_shared:
+        _req(global_state, torch.float32, "global_state", (T + 1, E, 1, A * O))
+    _req(action_mask, torch.uint8, "action_mask", (T + 1, E, A, n_actions))
+    _req(obs_step_count, torch.int32, "obs_step_count", (T + 1, E, A))
+    _req(action, torch.int32, "action", (T, E, A))
+    for name, t, dt in (("value", value, torch.float32), ("reward", reward, torch.float32),
+                        ("log_prob", log_prob, torch.float32), ("done", done, torch.uint8)):
+        _req(t, dt, name, (T, E, A))
+    _req(last_val, torch.float32, "last_val", (E, A))
+    _req(info_return, torch.float32, "info_return", (T, E))
+    _req(info_length, torch.int32, "info_length", (T, E))
+    _req(info_terminal, torch.uint8, "info_terminal", (T, E))
+    _req(env_state.step_count, torch.int32, "step_count", (E, A))
+    for name, t, dt in (("run_return", env_state.run_return, torch.float32), ("run_length", env_state.run_length, torch.int32),
+                        ("ep_return", env_state.ep_return, torch.float32), ("ep_length", env_state.ep_length, torch.int32)):
+        _req(t, dt, name, (E,))
+    rc = lib().mava_rollout_ff_f32(
+        ptr(actor_params), n_actions, ptr(critic_params), int(critic_shared), E, A, O, T, time_limit,
+        policy_seed & 0xFFFFFFFFFFFFFFFF, env_seed & 0xFFFFFFFFFFFFFFFF, t0 & 0xFFFFFFFF, row_offset & 0xFFFFFFFF,
+        env_offset & 0xFFFFFFFF, reward_mode, ptr(env_state.step_count), ptr(env_state.run_return),
+        ptr(env_state.run_length), ptr(env_state.ep_return), ptr(env_state.ep_length), ptr(agents_view),
+        ptr(global_state) if critic_shared else None, ptr(action_mask), ptr(obs_step_count), ptr(action), ptr(value),
+        ptr(reward), ptr(log_prob), ptr(done), ptr(last_val), ptr(info_return), ptr(info_length), ptr(info_terminal),
+        stream_ptr())
+    if rc == 1:
+        return False
+    check(rc, "mava_rollout_ff_f32")
+    return True

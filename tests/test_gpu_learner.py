@@ -82,10 +82,17 @@ def test_synthetic_env_bit_exact(dev, E, A, O, nA, S, tiled):
         assert np.array_equal(ts.observation.global_state.cpu().numpy()[:, 0], av[:, :, A:].reshape(E, A * O))
 
 
+@pytest.mark.parametrize("rollout,matmul", [("fused", "f16x2"), ("per-step", "f16x2"), ("per-step", "f32")])
 @pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])
-def test_learner_update_matches_oracle(dev, system, U):
+def test_learner_update_matches_oracle(dev, system, U, rollout, matmul, monkeypatch):
+    """fused: the whole rollout in one launch (rollout_h2.hip) + the f16x2 gradient kernels (the default configuration);
+    per-step: mava_policy_step_f32 + mava_synth_rware_step per time step (HIP graph from the second update on), with
+    the f16x2 or the exact-f32 gradient kernels."""
     from mava_amd import envs
     from mava_amd.systems.ppo import ff_ippo, ff_mappo
+
+    monkeypatch.setenv("MAVA_FUSED_ROLLOUT", "1" if rollout == "fused" else "0")
+    monkeypatch.setenv("MAVA_MATMUL", matmul)
 
     E, A, O, nA, T, K, M = 8, 2, 10, 5, 16, 2, 2
     cfg = _cfg(system, A, E, T, K, M, U)
@@ -132,7 +139,10 @@ def test_learner_update_matches_oracle(dev, system, U):
         assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
         assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
     assert L.count.cpu().tolist() == [4 * K * M, 4 * K * M]
-    assert len(L._graphs) == 1, "ONE rollout graph must serve every update index n"
+    if rollout == "per-step":
+        assert len(L._graphs) == 1, "ONE rollout graph must serve every update index n"
+    else:
+        assert L.fused_rollout and not L._graphs, "the fused rollout kernel did not run"
 
 
 def test_graph_rollout_is_bit_identical(dev, monkeypatch):
@@ -141,6 +151,7 @@ def test_graph_rollout_is_bit_identical(dev, monkeypatch):
     from mava_amd.systems.ppo import ff_mappo
 
     finals = []
+    monkeypatch.setenv("MAVA_FUSED_ROLLOUT", "0")  # this test is about the per-step launches and their HIP graph
     for flag in ("1", "0"):
         monkeypatch.setenv("MAVA_GRAPH_ROLLOUT", flag)
         cfg = _cfg("ff_mappo", 4, 16, 8, 2, 2, 2)

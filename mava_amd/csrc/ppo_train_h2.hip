@@ -71,9 +71,9 @@ H2Layout make_h2_layout(bool actor) {
   // partial logits (f32) live inside an image that is idle between barriers A and B2: dz2's (actor), dz1's (critic)
   L.yp = actor ? L.dz2 : L.dz1;
   L.agg = L.dy + (actor ? 2 * DY_PLANE : 0);
-  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[32] | misc[16] | W3[128] (critic) | c[128] | db2[128]
+  L.small = L.agg + 8 * 33 * 4;  // f32: b2[128] | b3[32] | misc[16] | W3[128] (critic)
   L.small = (L.small + 15) & ~15;
-  L.end = L.small + (128 + 32 + 16 + 128 + 128 + 128) * 4;
+  L.end = L.small + (128 + 32 + 16 + 128) * 4;
   return L;
 }
 constexpr int W2_PLANE = 128 * IMG_ROW;
@@ -121,14 +121,6 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   float* const B3s = B2s + 128;
   float* const misc = B3s + 32;
   float* const W3s = misc + 16;  // critic: the 128 head weights (read per tile: head on the VALU, dz2 = W3[f] * dy)
-  // Centred hidden layer.  h1 >= 0 has a large mean, and a weight's f16x2 representation error (the same in every
-  // row) times that mean shifts z2 coherently in all rows - invisible at 1e-4 except in a gradient that cancels to
-  // 1 / sqrt(rows) of its terms (the value loss at 10^6 rows).  So the h1 image holds h1 - c, c[k] = the mean of feature
-  // k over the block's first tile, and the constant part moves, exactly, to where f32 handles it:
-  //   z2 = (b2 + c.W2) + (h1 - c).W2            the bracket is computed once in f64 from the f32 weights
-  //   dW2[k][n] = sum_rows (h1 - c)[k] dz2[n]  +  c[k] * db2[n]      added in the epilogue
-  float* const Cs = W3s + 128;
-  float* const DB2 = Cs + 128;
   const int xs_row = L.xs_row, xs_plane = L.xs_plane;
 
   const int tid = threadIdx.x & 255;  // thread of its 4-wave group
@@ -405,7 +397,6 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
   const int w2row = (32 * w + r) * IMG_ROW + 16 * h;           // + 32 s: W2[32w + r][16s + 8h .. + 7]
   int buf = 0;
-  bool first = true;  // the block's first tile fixes the centring vector c (block-uniform flag)
 
   STAMP_DECL
   for (; it < ntiles; it += gridDim.x, buf ^= (WIDE ? 0 : 1)) {
@@ -451,36 +442,9 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       acc[q] = fmaxf(acc[q], 0.0f);
       relu1 |= (acc[q] > 0.0f) ? (1u << q) : 0u;
     }
-    if (first) {
-      // c[k] = mean of h1[.][k] over this (first) tile's 32 rows: xor tree over the row lanes of each half
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float v = acc[q];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-        if (r == 0) Cs[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * (1.0f / 32.0f);
-      }
-    }
-    }  // CHAIN
-    if (first) {
-      __syncthreads();  // c complete
-      if constexpr (CHAIN) {
-        if (tid < 128) {  // b2 + c . W2[:, tid] in f64 from the f32 weights
-          double sum = (double)B2s[tid];
-          for (int k = 0; k < 128; ++k) sum += (double)Cs[k] * (double)P[oW2 + k * MLP_H + tid];
-          B2s[tid] = (float)sum;
-        }
-      }
-      __syncthreads();
-      first = false;
-    }
-    if constexpr (CHAIN) {
     {
-      f32x16 hc;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) hc[q] = acc[q] - Cs[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
       half4 ph[4], pl[4];
-      write_image(H1I, r, 32 * w + 4 * h, hc, ph, pl);
+      write_image(H1I, r, 32 * w + 4 * h, acc, ph, pl);
     }
     }  // CHAIN
     STAMP(1);
@@ -786,26 +750,16 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   }
   if constexpr (CHAIN) {
 #pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) slab[oW2 + mlp_feat(t, q, h) * MLP_H + 32 * w + r] = gW2[t][q] * invR;
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
       float v = ab2[q];
 #pragma unroll
       for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-      if (r == 0) {
-        slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
-        DB2[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v;  // R x db2, for the centring term of dW2
-      }
+      if (r == 0) slab[oB2 + 32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] = v * invR;
     }
-  }
-  __syncthreads();
-  if constexpr (CHAIN) {
-    const float db2n = DB2[32 * w + r];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = mlp_feat(t, q, h);
-        slab[oW2 + k * MLP_H + 32 * w + r] = fmaf(Cs[k], db2n, gW2[t][q]) * invR;
-      }
   }
   float* red = reinterpret_cast<float*>(lds + L.h1);  // epilogue scratch (the tile loop is over)
   if constexpr (!CHAIN) {

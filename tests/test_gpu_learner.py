@@ -101,7 +101,7 @@ def test_learner_update_matches_oracle(dev, system, U, rollout, matmul, monkeypa
     # g / (sqrt(v) + eps) then amplifies the relative error of the few gradient entries near eps (1e-5).
     ftol = 1e-5 if matmul == "f32" else 5e-5
     utol = 1e-3 if matmul == "f32" else 1e-2
-    ptol = 1e-5 if matmul == "f32" else 3e-5
+    ptol = 1e-5 if matmul == "f32" else 1e-4
 
     E, A, O, nA, T, K, M = 8, 2, 10, 5, 16, 2, 2
     cfg = _cfg(system, A, E, T, K, M, U)

@@ -75,6 +75,10 @@ def run_critic(tag, idx_np, n_slab, agg, mode=0):
     g = out.cpu().numpy()
     print(f"[critic {tag}] value loss got {g[fc.size]:.9f} want {acc_c[1]:.9f} rel {abs(g[fc.size] - acc_c[1]) / acc_c[1]:.2e}")
     seg_report(tag, g[:fc.size], acc_c[2], dc, 1)
+    o3 = dc * 128 + 128 + 16384 + 128
+    e3 = g[o3:o3 + 128] - acc_c[2][o3:o3 + 128]
+    print(f"    dW3 signed error: mean {e3.mean():+.2e} rms {np.sqrt((e3 ** 2).mean()):.2e}  corr with mean-h2 proxy |want| {np.corrcoef(e3, acc_c[2][o3:o3 + 128])[0, 1]:+.2f};"
+          f" db3 err {g[o3 + 128] - acc_c[2][o3 + 128]:+.2e} (want {acc_c[2][o3 + 128]:+.3e})")
     lib().mava_ppo_set_critic_aggregation(1)
     lib().mava_ppo_set_matmul_mode(0)
 
@@ -93,10 +97,7 @@ def run_actor(tag, idx_np, n_slab, mode):
     lib().mava_ppo_set_matmul_mode(0)
 
 run_critic("f32 agg 256 slabs", idx, 256, 1)
-run_critic("f32 agg 64 slabs", idx, 64, 1)
-run_critic("f32 agg sorted idx", np.sort(idx), 256, 1)
-run_critic("f32 no-agg 256 slabs", idx, 256, 0)
+run_critic("f16x2 agg 256 slabs", idx, 256, 1, mode=1)
+run_critic("f16x2 no-agg 256 slabs", idx, 256, 0, mode=1)
 run_actor("f32 256 slabs", idx, 256, 0)
 run_actor("f16x2 256 slabs", idx, 256, 1)
-run_actor("f16x2 64 slabs", idx, 64, 1)
-run_actor("f16x2 sorted idx", np.sort(idx), 256, 1)

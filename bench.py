@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
+# f16x2 arithmetic: every f32-equivalent product costs three f16 MFMAs, so the algorithmic (f32-equivalent) FLOP rate
+# is priced against a third of the dense f16 peak
+F16X2_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (6290 GB/s measured float4 copy)
 
 
@@ -251,6 +255,7 @@ def main() -> None:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.matmul == "f32" else "f32 via 2 x f16 split operands on the MFMA (3 products, f32 accumulate)",
+        "matmul_mode": args.matmul,
         "data": "synthetic",
         "config": {"workload": (f"{args.system} ContinuousActionHead, MaBrax-shaped synthetic obs, " if continuous else
                                 f"{args.system} {args.env.upper()} {args.scenario}-shaped synthetic obs, ") + f"{E * U} envs/GPU "
@@ -264,7 +269,7 @@ def main() -> None:
     # run - it is attached from the committed rocprofv3 PMC pass of the same workload named in `traffic_source`
     # (regenerated per round with tools/pmc_traffic.sh; stale once a kernel changes after that pass).
     traffic, traffic_source = {}, None
-    for name in ("r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
+    for name in ("r02_v2_pmc_traffic.json", "r02_v1_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["kernels"]
@@ -292,15 +297,26 @@ def main() -> None:
         flop_a = (3 * fwd_a - 2 * L.Oa * 128) * rows
         tf_c = flop_c / (avg["critic_grad"] * 1e-3) / 1e12
         tf_a = flop_a / (avg["actor_grad"] * 1e-3) / 1e12
-        roof_c = {"kernel": "ppo_train_kernel<critic> (fused fwd+loss+bwd+dW)" + (", agents of a row aggregated" if aggregated else ""),
-                  "bound": "mfma", "achieved": tf_c, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": tf_c / F32_MFMA_PEAK_TFLOPS,
-                  "traffic": (traffic.get("ppo_train_kernel<critic>", {}).get("hbm_bytes_corrected") if default_shape else None),
+        # which kernels ran: the split-f16 ones (ppo_train_h2.hip) for the widths they instantiate, else exact f32
+        h2_a = args.matmul == "f16x2" and L.Oa <= 287 and not continuous
+        h2_c = args.matmul == "f16x2" and L.Oc <= 287
+        peak_a = F16X2_PEAK_TFLOPS if h2_a else F32_MFMA_PEAK_TFLOPS
+        peak_c = F16X2_PEAK_TFLOPS if h2_c else F32_MFMA_PEAK_TFLOPS
+        kname = lambda h2, net: (f"ppo_train_h2_kernel<{net}> (fused fwd+loss+bwd+dW, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
+                                 if h2 else f"ppo_train_kernel<{net}> (fused fwd+loss+bwd+dW, exact-f32 MFMA)")
+        tkey = lambda h2, net: next((k for k in traffic if k.startswith("ppo_train_h2_kernel" if h2 else "ppo_train_kernel")
+                                     and (("true" in k.split(",")[2]) == (net == "actor") if h2 else net in k)), None)
+        roof_c = {"kernel": kname(h2_c, "critic") + (", agents of a row aggregated" if aggregated else ""),
+                  "bound": "mfma", "achieved": tf_c, "peak": peak_c, "unit": "TFLOP/s",
+                  "frac": tf_c / peak_c,
+                  "traffic": (traffic.get(tkey(h2_c, "critic"), {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "mfma_busy_pmc": (traffic.get(tkey(h2_c, "critic"), {}).get("mfma_util") if default_shape else None),
                   "traffic_source": traffic_source if default_shape else None,
                   "avg_launch_ms": avg["critic_grad"], "flop_per_launch": flop_c, "rows_per_launch": rows_c}
-        roof_a = {"kernel": "ppo_train_kernel<actor> (fused fwd+loss+bwd+dW)", "bound": "mfma", "achieved": tf_a,
-                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_a / F32_MFMA_PEAK_TFLOPS,
-                  "traffic": (traffic.get("ppo_train_kernel<actor>", {}).get("hbm_bytes_corrected") if default_shape else None),
+        roof_a = {"kernel": kname(h2_a, "actor"), "bound": "mfma", "achieved": tf_a,
+                  "peak": peak_a, "unit": "TFLOP/s", "frac": tf_a / peak_a,
+                  "traffic": (traffic.get(tkey(h2_a, "actor"), {}).get("hbm_bytes_corrected") if default_shape else None),
+                  "mfma_busy_pmc": (traffic.get(tkey(h2_a, "actor"), {}).get("mfma_util") if default_shape else None),
                   "traffic_source": traffic_source if default_shape else None,
                   "avg_launch_ms": avg["actor_grad"], "flop_per_launch": flop_a, "rows_per_launch": rows}
         # "roofline" = the dominant kernel of the update (most time per update)
@@ -308,26 +324,48 @@ def main() -> None:
             out["roofline"], out["roofline_critic"] = roof_a, roof_c
         else:
             out["roofline"], out["roofline_actor"] = roof_c, roof_a
-        gae_bytes = 17 * T * E * A + 4 * E * A
-        gbs = gae_bytes / (avg["gae"] * 1e-3) / 1e9
-        out["roofline_gae"] = {"kernel": "gae_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy_peak": gbs / 6290.0,
-                               "traffic": (traffic.get("gae_kernel", {}).get("hbm_bytes_corrected") if default_shape else None),
-                               "avg_launch_us": avg["gae"] * 1e3, "bytes_per_launch": gae_bytes}
-        # An event pair around a ~10 us kernel adds ~3 us of its own; the committed rocprofv3 kernel trace of this
-        # command (profiles/r01_v6_kernel_stats.csv) has the kernel's own duration in the same loop.
-        if default_shape:
-            try:
-                import csv
+        # GAE.  With the fused rollout (the default) the scan runs in the rollout kernel's tail on data each workgroup
+        # has just written - there is no GAE launch in the loop.  The standalone kernel (mava_gae_f32: recurrent systems,
+        # per-step rollout, other callers) is measured here on the rollout's own outputs, outside the timed region:
+        # back-to-back launches (its 35.7 MB of inputs and outputs resident in the 256 MB Infinity Cache) and behind a
+        # 1 GiB fill (inputs from HBM: the rate of a device-to-device copy of the same bytes).
+        from mava_amd import ops as _ops
 
-                with open(os.path.join(ROOT, "profiles", "r01_v6_kernel_stats.csv")) as f:
-                    for row in csv.DictReader(f):
-                        if "gae_kernel" in row["Name"]:
-                            us = float(row["AverageNs"]) / 1e3
-                            out["roofline_gae"]["rocprof_avg_launch_us"] = us
-                            out["roofline_gae"]["rocprof_frac"] = gae_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-            except (OSError, ValueError, KeyError):
-                pass
+        rep0 = L.reps[0]
+        EA_ = E * A
+        g_args = (rep0.reward.view(T, EA_), rep0.value.view(T, EA_), rep0.done.view(T, EA_), rep0.last_val.view(EA_), 0.99, 0.95)
+        g_out = (torch.empty(T, EA_, device=dev), torch.empty(T, EA_, device=dev))
+        flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+
+        def _time_gae(cold: bool, n: int = 10):
+            ts = []
+            for _ in range(n):
+                if cold:
+                    flush.fill_(1.0)
+                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0_.record()
+                _ops.gae(*g_args, out=g_out)
+                e1_.record()
+                torch.cuda.synchronize()
+                ts.append(e0_.elapsed_time(e1_))
+            ts.sort()
+            return ts[len(ts) // 2]
+
+        _time_gae(False, 3)
+        warm_ms, cold_ms = _time_gae(False), _time_gae(True)
+        del flush
+        gae_bytes = 17 * T * E * A + 4 * E * A
+        gbs = gae_bytes / (warm_ms * 1e-3) / 1e9
+        gbs_cold = gae_bytes / (cold_ms * 1e-3) / 1e9
+        out["roofline_gae"] = {"kernel": "gae_kernel (standalone mava_gae_f32; the fused rollout runs GAE in its own tail, no launch in the loop)",
+                               "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "state": "back-to-back launches: operands resident in the Infinity Cache; HIP-event pair around one launch (adds ~3 us)",
+                               "frac_of_measured_copy_peak": gbs / 6290.0,
+                               "cold": {"achieved": gbs_cold, "frac": gbs_cold / HBM_PEAK_GBS, "avg_launch_us": cold_ms * 1e3,
+                                        "state": "behind a 1 GiB fill: operands from HBM"},
+                               "traffic": (traffic.get(next((k for k in traffic if k.startswith("gae_kernel")), ""), {}).get("hbm_bytes_corrected")
+                                           if default_shape else None),
+                               "avg_launch_us": warm_ms * 1e3, "bytes_per_launch": gae_bytes}
         adam_bytes = 28 * L.P
         out["roofline_adam"] = {"kernel": "clip_adam_kernel", "bound": "hbm (launch-bound at 77K params)",
                                 "achieved": adam_bytes / (avg["clip_adam"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -191,6 +191,8 @@ int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int 
  *      critic_shared 1: centralised critic on global_state (T+1, E, A*O), one value per env broadcast to its agents;
  *      0: decentralised critic on agents_view (global_state unused).  Slot 0 of agents_view / global_state /
  *      action_mask must hold the current observation; slots 1..T are written, the env state is advanced in place.
+ *      adv / tgt (T, E, A) or both NULL: when given, every (env, agent) column's GAE (ff_mappo.py:112-139, sequential
+ *      f32 recurrence) runs in the kernel's tail on the rewards / values / dones just written - no separate pass.
  *      Returns 0, a negative error, or 1 when the shape is not instantiated (the caller then runs mava_policy_step_f32
  *      + mava_synth_rware_step per step): needs 64 % A == 0, n_actions <= 8, the RWARE-style global state. */
 int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* critic_params, int critic_shared,
@@ -200,7 +202,7 @@ int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* c
                         int32_t* ep_length, float* agents_view, float* global_state, uint8_t* action_mask,
                         int32_t* obs_step_count, int32_t* action, float* value, float* reward, float* log_prob,
                         uint8_t* done, float* last_val, float* info_return, int32_t* info_length,
-                        uint8_t* info_terminal, mava_stream_t s);
+                        uint8_t* info_terminal, float* adv, float* tgt, float gamma, float gae_lambda, mava_stream_t s);
 
 /* ---- recurrent systems (rec_ippo / rec_mappo): mava/networks.py:238-331 (ScannedRNN GRU with
  *      reset-on-done, RecurrentActor, RecurrentValueNet), mava/systems/ppo/rec_mappo.py:91-149,

@@ -52,6 +52,8 @@ struct RolloutArgs {
   int32_t* action; float* value; float* reward; float* log_prob; uint8_t* done;  // (T, E, A)
   float* last_val;         // (E, A)
   float* info_return; int32_t* info_length; uint8_t* info_terminal;  // (T, E)
+  float* adv; float* tgt;  // (T, E, A) or null: GAE of ff_mappo.py:112-139 in the kernel's tail
+  float gamma, lam;
 };
 
 struct RolloutLds {  // byte offsets
@@ -462,7 +464,40 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   }
   // ------------------------------------------------------------------ bootstrap value (ff_mappo.py:109-110)
   forward(!ACT_ROLE);
-  if (!ACT_ROLE && tid < 64 && (e0 + tid / A) < E) a.last_val[(long)e0 * A + tid] = value_of(SHARED ? tid / A : tid);
+  if (bk_on) {
+    const float lv = value_of(SHARED ? tid / A : tid);
+    a.last_val[bk_k] = lv;
+    if (a.adv != nullptr) {
+      // GAE (ff_mappo.py:117-136) for this thread's (env, agent) column, reading back the reward / value / done it
+      // wrote itself during the rollout: delta = r + gamma V' (1 - d) - V; gae = delta + gamma lambda (1 - d) gae.
+      // Eight steps' loads go out together, then the sequential f32 recurrence; no separate pass over the trajectory.
+      float g = 0.0f, nv = lv;
+      const float gl = a.gamma * a.lam;
+      for (int tb = a.T; tb > 0; tb -= 8) {
+        float rw[8], vv[8];
+        uint8_t dd[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = tb - 1 - i;
+          const long k = (long)(t >= 0 ? t : 0) * EA + bk_k;
+          rw[i] = a.reward[k]; vv[i] = a.value[k]; dd[i] = a.done[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = tb - 1 - i;
+          if (t >= 0) {
+            const float nd = dd[i] ? 0.0f : 1.0f;
+            const float delta = rw[i] + a.gamma * nv * nd - vv[i];
+            g = delta + gl * nd * g;
+            const long k = (long)t * EA + bk_k;
+            a.adv[k] = g;
+            a.tgt[k] = g + vv[i];
+            nv = vv[i];
+          }
+        }
+      }
+    }
+  }
   if (bk_on) {
     a.step_count[bk_k] = sc_reg;
     if (bk_ag == 0) {
@@ -507,7 +542,8 @@ extern "C" int mava_rollout_ff_f32(const float* actor_params, int n_actions, con
                                    int32_t* ep_length, float* agents_view, float* global_state, uint8_t* action_mask,
                                    int32_t* obs_step_count, int32_t* action, float* value, float* reward, float* log_prob,
                                    uint8_t* done, float* last_val, float* info_return, int32_t* info_length,
-                                   uint8_t* info_terminal, hipStream_t s) {
+                                   uint8_t* info_terminal, float* adv, float* tgt, float gamma, float gae_lambda,
+                                   hipStream_t s) {
   MAVA_ARG_CHECK(E >= 1 && A >= 1 && O >= 2 && T >= 1 && n_actions >= 1 && time_limit >= 1, 0,
                  "mava_rollout_ff_f32: bad shape E=%d A=%d O=%d T=%d nA=%d", E, A, O, T, n_actions);
   MAVA_ARG_CHECK(actor_params && critic_params && step_count && run_return && run_length && ep_return && ep_length &&
@@ -528,6 +564,8 @@ extern "C" int mava_rollout_ff_f32(const float* actor_params, int n_actions, con
   a.action_mask = action_mask; a.obs_step_count = obs_step_count; a.action = action; a.value = value; a.reward = reward;
   a.log_prob = log_prob; a.done = done; a.last_val = last_val; a.info_return = info_return; a.info_length = info_length;
   a.info_terminal = info_terminal;
+  MAVA_ARG_CHECK((adv == nullptr) == (tgt == nullptr), 1, "mava_rollout_ff_f32: adv and tgt go together");
+  a.adv = adv; a.tgt = tgt; a.gamma = gamma; a.lam = gae_lambda;
   if (critic_shared) {
     if (s1a == 5 && s1c == 17 && A >= 4) return launch_rollout<8, 5, 17, true>(a, s);  // RWARE tiny / small-4ag (O 66, A 4)
 #ifndef MAVA_FAST_BUILD

@@ -291,8 +291,8 @@ class FFLearner:
         self.t_global += self.T
 
     def _rollout_fused(self, n: int) -> bool:
-        """ff_mappo.py:76-110 + GAE: one launch per replica for all T acting + env steps and the bootstrap value
-        (mava_rollout_ff_f32), then the GAE kernel.  False when the library does not instantiate the shape."""
+        """ff_mappo.py:76-139: one launch per replica for all T acting + env steps, the bootstrap value and GAE
+        (mava_rollout_ff_f32).  False when the library does not instantiate the shape."""
         s = self.config.system
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         EA = self.E * self.A
@@ -306,16 +306,14 @@ class FFLearner:
                 global_state=rep.global_state, action_mask=rep.action_mask, obs_step_count=rep.step_count,
                 action=rep.action, value=rep.value, reward=rep.reward, log_prob=rep.log_prob, done=rep.done,
                 last_val=rep.last_val, info_return=rep.info_return[n], info_length=rep.info_length[n],
-                info_terminal=rep.info_terminal[n])
+                info_terminal=rep.info_terminal[n], adv=rep.adv, tgt=rep.tgt, gamma=float(s.gamma),
+                gae_lambda=float(s.gae_lambda))
             if not ok:
                 assert u == 0
                 self.fused_rollout = False
                 return False
             rep.last_reward.copy_(rep.reward[self.T - 1])
             rep.last_done.copy_(rep.done[self.T - 1])
-            self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
-                        rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
-                        out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
         self.step_dev.add_(self.T)
         return True
 

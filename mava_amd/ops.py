@@ -389,7 +389,8 @@ def slab_reduce2(slab: torch.Tensor, n_main: int, out_main: torch.Tensor, n_tail
 def rollout_ff(actor_params, critic_params, *, n_actions: int, critic_shared: bool, E: int, A: int, O: int, T: int,
                time_limit: int, policy_seed: int, env_seed: int, t0: int, row_offset: int, env_offset: int,
                reward_mode: int, env_state, agents_view, global_state, action_mask, obs_step_count, action, value,
-               reward, log_prob, done, last_val, info_return, info_length, info_terminal) -> bool:
+               reward, log_prob, done, last_val, info_return, info_length, info_terminal, adv=None, tgt=None,
+               gamma: float = 0.99, gae_lambda: float = 0.95) -> bool:
     """The whole rollout of one replica in one launch (mava_rollout_ff_f32).  Returns False when the library does not
     instantiate the shape - the caller then steps policy_step / env.step_into per time step."""
     W = A + O
@@ -409,6 +410,9 @@ def rollout_ff(actor_params, critic_params, *, n_actions: int, critic_shared: bo
                         ("log_prob", log_prob, torch.float32), ("done", done, torch.uint8)):
         _req(t, dt, name, (T, E, A))
     _req(last_val, torch.float32, "last_val", (E, A))
+    if adv is not None or tgt is not None:
+        _req(adv, torch.float32, "adv", (T, E, A))
+        _req(tgt, torch.float32, "tgt", (T, E, A))
     _req(info_return, torch.float32, "info_return", (T, E))
     _req(info_length, torch.int32, "info_length", (T, E))
     _req(info_terminal, torch.uint8, "info_terminal", (T, E))
@@ -423,7 +427,7 @@ def rollout_ff(actor_params, critic_params, *, n_actions: int, critic_shared: bo
         ptr(env_state.run_length), ptr(env_state.ep_return), ptr(env_state.ep_length), ptr(agents_view),
         ptr(global_state) if critic_shared else None, ptr(action_mask), ptr(obs_step_count), ptr(action), ptr(value),
         ptr(reward), ptr(log_prob), ptr(done), ptr(last_val), ptr(info_return), ptr(info_length), ptr(info_terminal),
-        stream_ptr())
+        ptr(adv), ptr(tgt), gamma, gae_lambda, stream_ptr())
     if rc == 1:
         return False
     check(rc, "mava_rollout_ff_f32")

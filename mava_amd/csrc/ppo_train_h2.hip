@@ -84,17 +84,22 @@ constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 i
 __global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, int steps, uint4* __restrict__ out) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   float carry = 0.0f;  // error diffusion along k over this lane's inputs of feature 32w + r (split1_carry)
-  for (int s = 0; s < steps; ++s) {
-    float v[8];
+  for (int s0 = 0; s0 < steps; s0 += 6) {  // steps is a multiple of 6; six steps' loads in flight at a time
+    float v[6][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 16 * s + 8 * h + e;
-      v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * (s0 + i) + 8 * h + e;
+        v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+      }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const Frag f = split8_carry(v[i], carry);
+      const int gid = (s0 + i) * 256 + threadIdx.x;
+      out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
+      out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
     }
-    const Frag f = split8_carry(v, carry);
-    const int gid = s * 256 + threadIdx.x;
-    out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
-    out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
   }
 }
 

@@ -211,18 +211,26 @@ int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* c
  *      is time-major: row = t*Rm + m, m = (local env)*A + agent; external trajectory arrays are (T,E,A,..)
  *      and env ids come from idx (Rm/A entries, a slice of the env permutation) or the identity. */
 
-/* Y = act(X W + b) [masked by gate > 0]; X is T32 (rows x K) or, with x_rowmajor, the external row-major
- * source (row stride x_ld >= K, so a call can read a column block) gathered per batch row; W (K x N)
- * row-major with row stride ldw; Y T32 (rows x N).  accumulate: start from the existing Y (K-chunked
- * products for inputs wider than 384). */
+/* Y = act(X W + b) [masked by gate > 0]; X is T32 (x_ld >= K features per 32-row tile, the first K used; x_ld <= 0
+ * means K) or, with x_rowmajor, the external row-major source (row stride x_ld >= K, so a call can read a column
+ * block) gathered per batch row; W (K x N) row-major with row stride ldw; Y T32 (rows x N).  accumulate: start from
+ * the existing Y (K-chunked products for inputs wider than 384).  With mava_ppo_set_matmul_mode(1) T32 inputs run on
+ * split-f16 operands (rec_dense_h2.hip: 3 f16 MFMAs per product, f32 accumulate, operands must sit in f16 range -
+ * see grad_scale below); row-major inputs always run the exact-f32 kernel. */
 int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                        int x_share, int x_ld, int accumulate, const float* w, int ldw, const float* bias,
                        const float* gate, float* y, int K, int N, int rows, int relu, mava_stream_t s);
 
-/* per-block slabs of dW = X^T Y (K x N row-major) followed by db = colsum(Y) when want_bias. */
+/* per-block slabs of out_scale * dW = X^T Y (K x N row-major) followed by out_scale * db = colsum(Y) when want_bias.
+ * out_scale undoes the grad_scale the backward chain was started with (1.0f when none). */
 int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                     int x_share, int x_ld, const float* y, int K, int N, int rows, int want_bias,
+                     int x_share, int x_ld, const float* y, int K, int N, int rows, int want_bias, float out_scale,
                      float* slab, long slab_stride, int n_slab, mava_stream_t s);
+/* Row-major, env-permuted observation slice of a minibatch (same gather description as mava_rec_dense_f32 with
+ * x_rowmajor) -> T32 matrix `out` with k_pad >= K features per tile (zeros past K): done once per minibatch, read by
+ * the pre-torso product and by its weight-gradient product as a plain T32 operand. */
+int mava_rec_gather_t32_f32(const float* x, const int32_t* idx, int Rm, int E, int A, int x_share, int x_ld, int K,
+                            int rows, int k_pad, float* out, mava_stream_t s);
 /* 0 (default): exact-f32 MFMAs; 1: X^T Y on six bf16 MFMAs per f32 product (operands split hi/mid/lo once while they are
  * staged; f32 accuracy, parity-tested; currently slower - see rec_dense.hip).  For A/B measurements. */
 int mava_rec_xty_set_variant(int v);
@@ -241,11 +249,14 @@ int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const
                           float* dgi, float* dgh, mava_stream_t s);
 
 /* sequence losses on T32 logits / values: rec_mappo.py:210-242 and :244-266 (after the re-unroll);
- * loss_partials: (n_blocks, 2) partial sums already divided by the element count. */
+ * loss_partials: (n_blocks, 2) partial sums already divided by the element count.  The gradient w.r.t. the network
+ * outputs is written TIMES grad_scale: loss gradients are O(1 / rows), below f16's normal range at 10^6 rows, so the
+ * backward chain (dense, BPTT scan - all linear in the gradient) runs in units of a power of two near `rows` and
+ * mava_rec_xty_f32(out_scale = 1 / grad_scale) returns to true units; exact in f32, 1.0f for none. */
 int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const int32_t* idx,
                             const float* logits, const uint8_t* mask, const int32_t* action,
                             const float* old_log_prob, const float* advantages, const double* adv_stats,
-                            int n_stats, float clip_eps, float ent_coef, float* dlogits,
+                            int n_stats, float clip_eps, float ent_coef, float grad_scale, float* dlogits,
                             float* loss_partials, int n_blocks, mava_stream_t s);
 /* Continuous head on the recurrent systems (rec_mappo.py:210-242 with networks.py:127-169): `mean` / `dmean` are T32
  * (T*Rm x action_dim) like logits / dlogits of mava_seq_actor_loss_f32, `action` is the external (T, E, A, action_dim)
@@ -255,8 +266,8 @@ int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_d
                                        const float* mean, const float* log_std, const float* action,
                                        const float* old_log_prob, const float* advantages, const double* adv_stats,
                                        int n_stats, float clip_eps, float ent_coef, uint64_t seed, uint32_t ent_step,
-                                       uint32_t row_offset, float* dmean, float* loss_partials, float* dscale_partials,
-                                       int n_blocks, mava_stream_t s);
+                                       uint32_t row_offset, float grad_scale, float* dmean, float* loss_partials,
+                                       float* dscale_partials, int n_blocks, mava_stream_t s);
 /* rollout epilogue: T32 means of one step -> action (rows, action_dim) = tanh(loc + scale * noise), log_prob (rows) */
 int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std, uint64_t seed,
                                    uint32_t step, uint32_t row_offset, int greedy, float* action, float* log_prob,
@@ -267,7 +278,7 @@ int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, 
  * identical network passes. */
 int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_per_row, const int32_t* idx, const float* values,
                              const float* old_value, const float* targets, float clip_eps, float vf_coef,
-                             float* dvalues, float* loss_partials, int n_blocks, mava_stream_t s);
+                             float grad_scale, float* dvalues, float* loss_partials, int n_blocks, mava_stream_t s);
 
 /* rollout epilogue: masked Categorical sample + log_prob from T32 logits of one step (rows = E*A). */
 int mava_seq_sample_f32(int rows, int n_actions, const float* logits, const uint8_t* mask, uint64_t seed,

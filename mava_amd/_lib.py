@@ -52,7 +52,7 @@ _SIGNATURES = {
     "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32,
                                            u32, vp, lng, i32, vp],
     "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
-                                           u32, vp, vp, vp, i32, vp],
+                                           u32, f32, vp, vp, vp, i32, vp],
     "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_rec_xty_set_variant": [i32],
     "mava_adv_stats_blocks": [],
@@ -63,15 +63,16 @@ _SIGNATURES = {
     "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 14 + [vp, i32, vp],
     "mava_rollout_ff_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, u64, u64, u32, u32, u32, i32] + [vp] * 18 + [vp, vp, f32, f32, vp],
     "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, lng, i32, vp],
+    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp, lng, i32, vp],
+    "mava_rec_gather_t32_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "mava_gru_scan_bwd_f32": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, i32, vp],
+    "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32,
                                      vp, vp, i32, i32, vp, vp],
     "mava_rec_step_f32": [vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp,
                           i32, i32, vp, vp],
-    "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp],
+    "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
     "mava_seq_sample_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_t32_convert_f32": [vp, i32, i32, i32, vp, vp],
 }

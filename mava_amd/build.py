@@ -26,7 +26,9 @@ HIP_SOURCES = [
     "rollout_h2.hip",
     "synth_rware.hip",
     "rec_dense.hip",
+    "rec_dense_h2.hip",
     "rec_gru.hip",
+    "rec_gru_h2.hip",
     "rec_step.hip",
 ]
 CPP_SOURCES = ["api.cpp"]

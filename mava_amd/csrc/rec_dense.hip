@@ -14,32 +14,11 @@
 //   input is T32.
 // mava_rec_xty_f32:    dW = X^T Y, db = colsum(Y) as per-block slabs (fixed-order reduction elsewhere).
 #include "mlp_core.h"
+#include "rec_task.h"
+
+extern "C" int mava_ppo_get_matmul_mode(void);
 
 namespace {
-
-struct DenseTask {
-  const float* x;        // T32 (rows x K) or row-major gather source
-  int x_rowmajor;        // 1: x is row-major (rows_x x K); row r of the batch reads x[xrow(r)]
-  // row-major gather (time-major trajectory): batch row q -> t = q / Rm, m = q % Rm, env = idx[m / A],
-  // agent = m % A, source row = ((t * E + env) * A + agent) / xshare
-  const int32_t* idx;    // (Rm / A) env ids of the minibatch, or null (identity)
-  int Rm, E, A, xshare;
-  int x_ld;              // row stride (floats) of the row-major source (>= K; lets a call read a column block)
-  int accumulate;        // 1: start from the existing y (T32) instead of the bias (K-chunked products)
-  const float* w;        // (K x N) row-major, row stride ldw
-  int ldw;
-  const float* bias;     // (N) or null
-  const float* gate;     // T32 (rows x N) or null: output multiplied by (gate > 0)
-  float* y;              // T32 (rows x N)
-  int K, N, rows, relu;
-};
-
-__device__ __forceinline__ long gather_row(const DenseTask& tk, int q) {
-  const int t = q / tk.Rm, m = q - t * tk.Rm;
-  const int e_local = m / tk.A, a = m - e_local * tk.A;
-  const int env = tk.idx ? tk.idx[e_local] : e_local;
-  return ((long)((long)t * tk.E + env) * tk.A + a) / tk.xshare;
-}
 
 // NB = K padded to 16-input batches; NTW = 32-feature output tiles per wave (tiles w, w+4, w+8)
 // RM: row-major gathered input (else T32).  FULLK (T32 only): K == 16*NB, so operand addresses are
@@ -200,7 +179,8 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
                              : ((NB % 8 == 0) ? 8 : ((NB % 6 == 0) ? 6 : ((NB % 4 == 0) ? 4 : 2)));
     constexpr int PD = RDX - 1;
     static_assert(NB % RDX == 0, "ring depth must divide the batch count");
-    auto tile_ptr = [&](int it) { return tk.x + ((long)it * K + (FULLK ? h : 0)) * 32 + j; };
+    const int KX = tk.x_ld;  // features per x tile (>= K; the padded gather of rec_dense_h2.hip has more)
+    auto tile_ptr = [&](int it) { return tk.x + ((long)it * KX + (FULLK ? h : 0)) * 32 + j; };
     auto load_batch = [&](const float* xp, int bq, float (&dst)[8]) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -299,19 +279,6 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
   }
 }
 
-struct XtyTask {
-  const float* x;      // T32 (rows x K) or row-major gather source
-  int x_rowmajor;
-  const int32_t* idx;
-  int Rm, E, A, xshare;
-  int x_ld;
-  const float* y;      // T32 (rows x N)
-  int K, N, rows;
-  float* slab;         // (gridDim.x, slab_stride): [dW (K x N row-major) | db (N)]
-  long slab_stride;
-  int want_bias;
-};
-
 // KT = K tiles of 32, NTW = N tiles per wave (n-tiles w, w+4, w+8)
 template <int KT, int NTW>
 __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
@@ -350,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
       yq[i] = ysrc[q < ny4 ? q : (ny4 - 1)];
     }
     if (!tk.x_rowmajor) {
-      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * K) * 32);
+      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * tk.x_ld) * 32);
 #pragma unroll
       for (int i = 0; i < KT; ++i) {
         const int q = tid + 256 * i;
@@ -445,13 +412,13 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
       for (int r = 0; r < 16; ++r) {
         const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int n = 32 * (w + 4 * tw) + j;
-        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r];
+        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r] * tk.out_scale;
       }
   if (tk.want_bias) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int n = tid + 256 * u;
-      if (n < N) slab[(long)K * N + n] = bsum[u];
+      if (n < N) slab[(long)K * N + n] = bsum[u] * tk.out_scale;
     }
   }
 }
@@ -515,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_bf16x6_kernel(XtyTask tk) {
       yq[i] = ysrc[q < ny4 ? q : (ny4 - 1)];
     }
     if (!tk.x_rowmajor) {
-      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * K) * 32);
+      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * tk.x_ld) * 32);
 #pragma unroll
       for (int i = 0; i < KT; ++i) {
         const int q = tid + 256 * i;
@@ -630,13 +597,13 @@ __global__ __launch_bounds__(256, 1) void rec_xty_bf16x6_kernel(XtyTask tk) {
       for (int r = 0; r < 16; ++r) {
         const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int n = 32 * (w + 4 * tw) + j;
-        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r];
+        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r] * tk.out_scale;
       }
   if (tk.want_bias && (tid & 7) == 0) {
 #pragma unroll
     for (int i = 0; i < NT_ALL; ++i) {
       const int n = (tid >> 3) + 32 * i;
-      if (n < N) slab[(long)K * N + n] = bacc[i];
+      if (n < N) slab[(long)K * N + n] = bacc[i] * tk.out_scale;
     }
   }
 }
@@ -719,6 +686,7 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
                                   int x_share, int x_ld, int accumulate, const float* w, int ldw,
                                   const float* bias, const float* gate, float* y, int K, int N, int rows,
                                   int relu, hipStream_t s) {
+  if (!x_rowmajor && x_ld <= 0) x_ld = K;
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384 && ldw >= N, 0,
                  "mava_rec_dense_f32: K=%d N=%d ldw=%d unsupported (K, N <= 384)", K, N, ldw);
   MAVA_ARG_CHECK(rows >= 0 && rows % 32 == 0, 1, "mava_rec_dense_f32: rows=%d must be a multiple of 32", rows);
@@ -726,7 +694,14 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
   MAVA_ARG_CHECK(x && w && y, 2, "mava_rec_dense_f32: null pointer argument");
   MAVA_ARG_CHECK(!x_rowmajor || (Rm >= 1 && A >= 1 && E >= 1 && x_share >= 1 && rows % Rm == 0 && x_ld >= K), 3,
                  "mava_rec_dense_f32: bad gather description Rm=%d E=%d A=%d x_ld=%d", Rm, E, A, x_ld);
+  MAVA_ARG_CHECK(x_rowmajor || x_ld >= K, 5, "mava_rec_dense_f32: T32 input with %d features per tile < K=%d", x_ld, K);
   DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, accumulate, w, ldw, bias, gate, y, K, N, rows, relu};
+  if (mava_ppo_get_matmul_mode() == 1) {
+    const int rc = mava_rec_dense_h2_launch(tk, s);
+    if (rc <= 0) return rc;
+  }
+  MAVA_ARG_CHECK(x_rowmajor || x_ld == K || K % 16 == 0, 6,
+                 "mava_rec_dense_f32: a padded T32 input (K=%d of %d features) needs K %% 16 == 0 in the f32 kernel", K, x_ld);
   const int nb = (K + 15) / 16;
   const int ntw = ((N + 31) / 32 + 3) / 4;  // n-tiles per wave
   MAVA_ARG_CHECK(nb * ntw * 8 <= 192, 4, "mava_rec_dense_f32: weight slice of %d registers does not fit (K=%d N=%d)",
@@ -741,15 +716,20 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
 }
 
 extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
-                                int x_ld, const float* y, int K, int N, int rows, int want_bias, float* slab,
-                                long slab_stride, int n_slab, hipStream_t s) {
+                                int x_ld, const float* y, int K, int N, int rows, int want_bias, float out_scale,
+                                float* slab, long slab_stride, int n_slab, hipStream_t s) {
+  if (!x_rowmajor && x_ld <= 0) x_ld = K;
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384, 0, "mava_rec_xty_f32: K=%d N=%d unsupported", K, N);
   MAVA_ARG_CHECK(rows >= 32 && rows % 32 == 0 && n_slab >= 1 && n_slab <= 1024, 1,
                  "mava_rec_xty_f32: rows=%d n_slab=%d", rows, n_slab);
   MAVA_ARG_CHECK(slab_stride >= (long)K * N + (want_bias ? N : 0), 2, "mava_rec_xty_f32: slab_stride too small");
   MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
-  MAVA_ARG_CHECK(!x_rowmajor || x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
-  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, slab, slab_stride, want_bias};
+  MAVA_ARG_CHECK(x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
+  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, slab, slab_stride, want_bias, out_scale};
+  if (mava_ppo_get_matmul_mode() == 1 && g_xty_variant == 0) {
+    const int rc = mava_rec_xty_h2_launch(tk, n_slab, s);
+    if (rc <= 0) return rc;
+  }
   const int kt = (K + 31) / 32;
   const int ntw = ((N + 31) / 32 + 3) / 4;
   MAVA_ARG_CHECK(kt * ntw <= 12, 4, "mava_rec_xty_f32: %d accumulator tiles per wave do not fit (K=%d N=%d)", kt * ntw, K, N);

@@ -13,37 +13,15 @@
 // wave fed by 64 LDS reads of the (transposed) previous hidden state - no weight traffic at all.
 // Activations use the T32 tile layout (rec_dense.hip): accumulator-shaped loads/stores are coalesced.
 #include "mlp_core.h"
+#include "rec_task.h"
 #include "tanh_normal.h"
+
+extern "C" int mava_ppo_get_matmul_mode(void);
 
 namespace {
 
 constexpr int LDT = 33;
 constexpr int G3 = 3 * MLP_H;
-
-struct ScanTask {
-  int T, Rm, E, A;           // Rm sequences (multiple of 32); E envs in the external arrays
-  const int32_t* idx;        // (Rm / A) env ids or null
-  const uint8_t* done;       // external (T, E, A) u8: flag ENTERING each step
-  const float* h0;           // initial hidden state: T32 (Rm x 128) if h0_t32 else external (E, A, 128)
-  int h0_t32;
-  const float* wh;           // (128 x 384) row-major [hr | hz | hn]
-  const float* bhn;          // (128)
-  // forward
-  const float* gi;           // T32 (T*Rm x 384)
-  float* hs;                 // T32 (T*Rm x 128) h after each step
-  float* hprev;              // T32 (T*Rm x 128) masked h entering each step (null: not stored)
-  float* saved;              // T32 (T*Rm x 512) [r | z | n | hn_lin]     (null: not stored)
-  // backward
-  const float* dh_out;       // T32 (T*Rm x 128)
-  float* dgi;                // T32 (T*Rm x 384)
-  float* dgh;                // T32 (T*Rm x 384)
-};
-
-__device__ __forceinline__ long ext_row(const ScanTask& tk, int t, int m) {
-  const int e_local = m / tk.A, a = m - e_local * tk.A;
-  const int env = tk.idx ? tk.idx[e_local] : e_local;
-  return ((long)t * tk.E + env) * tk.A + a;
-}
 
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the scan's
 // elementwise phase runs with the MFMA pipe idle (one wave per SIMD), and libm's expf / tanhf / IEEE division cost
@@ -274,6 +252,7 @@ struct SeqLossTask {
   const double* stats;       // adv stats partials (actor)
   int n_stats;
   float clip_eps, coef;      // ent_coef (actor) / vf_coef (critic)
+  float grad_scale;          // dy is written in units of grad_scale (a power of two; see rec_dense_h2.hip)
   float* loss_partials;      // (gridDim.x, 2)
   // sampling (rollout)
   uint32_t seed_lo, seed_hi, step, row_offset;
@@ -295,6 +274,7 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossTask tk) {
   __shared__ float st[2];
   const long R = (long)tk.T * tk.Rm;
   const float invR = 1.0f / (float)(R * (ACTOR ? 1 : (tk.agg > 1 ? tk.agg : 1)));  // mean over all agent row-steps
+  const float gs = tk.grad_scale;
   if (ACTOR && threadIdx.x == 0) {
     double s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < tk.n_stats; ++i) { s1 += tk.stats[2 * i]; s2 += tk.stats[2 * i + 1]; }
@@ -341,7 +321,7 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossTask tk) {
           const float pl = (cat.p[o] > 0.0f) ? cat.logp[o] : 0.0f;
           float d = dlp * (oh - cat.p[o]) + ec * cat.p[o] * (pl + cat.entropy);
           if (cat.z[o] == -FLT_MAX) d = 0.0f;
-          tk.dy[(tile * tk.no + o) * 32 + jj] = d;
+          tk.dy[(tile * tk.no + o) * 32 + jj] = d * gs;
         }
       }
       la += -fminf(l1, l2) * invR;
@@ -365,7 +345,7 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossTask tk) {
         dsum += tk.coef * (g1 * e1 + g2 * e2) * invR;
         la += 0.5f * fmaxf(l1, l2) * invR;
       }
-      tk.dy[tile * 32 + jj] = dsum;
+      tk.dy[tile * 32 + jj] = dsum * gs;
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -486,7 +466,7 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       if (o < tk.no) {
-        tk.dy[(tile * tk.no + o) * 32 + jj] = dlp * dm[o] + ec * 2.0f * th[o];
+        tk.dy[(tile * tk.no + o) * 32 + jj] = (dlp * dm[o] + ec * 2.0f * th[o]) * tk.grad_scale;
         ds[o] += dlp * dsl[o] - ec * (1.0f / sc[o] - 2.0f * th[o] * ep[o]);
       }
     }
@@ -571,6 +551,7 @@ extern "C" int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t*
   ScanTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.h0 = h0; tk.h0_t32 = h0_t32;
   tk.wh = wh; tk.bhn = bhn; tk.gi = gi; tk.hs = hs; tk.hprev = hprev; tk.saved = saved;
+  if (mava_ppo_get_matmul_mode() == 1) return mava_gru_scan_fwd_h2_launch(tk, s);  // rec_gru_h2.hip
   hipLaunchKernelGGL(gru_scan_fwd_kernel, dim3(Rm / 32), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
@@ -587,6 +568,7 @@ extern "C" int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t*
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.wh = wh;
   tk.saved = const_cast<float*>(saved); tk.hprev = const_cast<float*>(hprev); tk.dh_out = dh_out;
   tk.dgi = dgi; tk.dgh = dgh;
+  if (mava_ppo_get_matmul_mode() == 1) return mava_gru_scan_bwd_h2_launch(tk, s);  // rec_gru_h2.hip
   hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(Rm / 32), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
@@ -595,7 +577,7 @@ extern "C" int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t*
 extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const int32_t* idx,
                                        const float* logits, const uint8_t* mask, const int32_t* action,
                                        const float* old_log_prob, const float* advantages, const double* adv_stats,
-                                       int n_stats, float clip_eps, float ent_coef, float* dlogits,
+                                       int n_stats, float clip_eps, float ent_coef, float grad_scale, float* dlogits,
                                        float* loss_partials, int n_blocks, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && n_actions >= 1 && n_actions <= 32 && n_blocks >= 1, 0,
                  "mava_seq_actor_loss_f32: bad shape");
@@ -605,6 +587,7 @@ extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_action
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.no = n_actions; tk.idx = idx; tk.y = logits; tk.dy = dlogits;
   tk.mask = mask; tk.action = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
   tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = ent_coef; tk.loss_partials = loss_partials;
+  tk.grad_scale = grad_scale;
   if (n_actions <= 8) hipLaunchKernelGGL((seq_loss_kernel<8, true>), dim3(n_blocks), dim3(256), 0, s, tk);
   else if (n_actions <= 16) hipLaunchKernelGGL((seq_loss_kernel<16, true>), dim3(n_blocks), dim3(256), 0, s, tk);
   else hipLaunchKernelGGL((seq_loss_kernel<32, true>), dim3(n_blocks), dim3(256), 0, s, tk);
@@ -616,7 +599,8 @@ extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, i
                                                   const float* mean, const float* log_std, const float* action,
                                                   const float* old_log_prob, const float* advantages,
                                                   const double* adv_stats, int n_stats, float clip_eps, float ent_coef,
-                                                  uint64_t seed, uint32_t ent_step, uint32_t row_offset, float* dmean,
+                                                  uint64_t seed, uint32_t ent_step, uint32_t row_offset,
+                                                  float grad_scale, float* dmean,
                                                   float* loss_partials, float* dscale_partials, int n_blocks,
                                                   hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && action_dim >= 1 && action_dim <= 16 && n_blocks >= 1, 0,
@@ -628,7 +612,7 @@ extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, i
   tk.log_std = log_std; tk.action_f = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
   tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = ent_coef; tk.loss_partials = loss_partials;
   tk.dscale_partials = dscale_partials; tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32);
-  tk.ent_step = ent_step; tk.row_offset = row_offset;
+  tk.ent_step = ent_step; tk.row_offset = row_offset; tk.grad_scale = grad_scale;
   if (action_dim <= 8) hipLaunchKernelGGL((seq_loss_cont_kernel<8>), dim3(n_blocks), dim3(256), 0, s, tk);
   else hipLaunchKernelGGL((seq_loss_cont_kernel<16>), dim3(n_blocks), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
@@ -654,8 +638,8 @@ extern "C" int mava_seq_sample_continuous_f32(int rows, int action_dim, const fl
 
 extern "C" int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_per_row, const int32_t* idx, const float* values,
                                         const float* old_value, const float* targets, float clip_eps,
-                                        float vf_coef, float* dvalues, float* loss_partials, int n_blocks,
-                                        hipStream_t s) {
+                                        float vf_coef, float grad_scale, float* dvalues, float* loss_partials,
+                                        int n_blocks, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && n_blocks >= 1 && agents_per_row >= 1 && (agents_per_row == 1 || A == 1), 0,
                  "mava_seq_critic_loss_f32: bad shape (agents_per_row > 1 needs A == 1: rows are (t, env) rows)");
   MAVA_ARG_CHECK(values && old_value && targets && dvalues && loss_partials, 1,
@@ -663,6 +647,7 @@ extern "C" int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_
   SeqLossTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.agg = agents_per_row; tk.no = 1; tk.idx = idx; tk.y = values; tk.dy = dvalues;
   tk.f0 = old_value; tk.f1 = targets; tk.clip_eps = clip_eps; tk.coef = vf_coef; tk.loss_partials = loss_partials;
+  tk.grad_scale = grad_scale;
   hipLaunchKernelGGL((seq_loss_kernel<1, false>), dim3(n_blocks), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;

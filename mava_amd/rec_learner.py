@@ -16,6 +16,7 @@ dense(post) -> dense(head) -> sequence loss -> dense(dpost) -> dense(dh) -> GRU 
 """
 from __future__ import annotations
 
+import math
 import os
 
 from typing import Any, Dict, List, Optional
@@ -79,6 +80,11 @@ class RecLearner:
         if self.E % self.M:
             raise ValueError("num_envs must be divisible by num_minibatches (rec_mappo.py:354-357)")
         self.n_upd = int(s.get("num_updates_per_eval", 1))
+        # arithmetic of the dense / X^T Y products on T32 operands: "f16x2" (default, rec_dense_h2.hip) or "f32"
+        self.matmul_mode = str(s.get("matmul_mode", None) or os.environ.get("MAVA_MATMUL", "f16x2"))
+        if self.matmul_mode not in ("f16x2", "f32"):
+            raise ValueError(f"system.matmul_mode must be 'f16x2' or 'f32', got {self.matmul_mode!r}")
+        lib().mava_ppo_set_matmul_mode(1 if self.matmul_mode == "f16x2" else 0)
         if env.num_envs != self.E:
             raise ValueError(f"env.num_envs={env.num_envs} != arch.num_envs={self.E}")
         if centralised_critic and not getattr(env, "add_global_state", False):
@@ -137,7 +143,9 @@ class RecLearner:
         self.seg_off = [0, self.Pa, self.P]
         self.seg_lr = [float(s.actor_lr), float(s.critic_lr)]
         self.ws_roll = RecWorkspace(self.E * self.A, max(self.nA, 1), d, training=False)
-        self.ws = RecWorkspace(self.T * self.Rm, max(self.nA, 1), d, training=True)
+        self.ws = RecWorkspace(self.T * self.Rm, max(self.nA, 1), d, training=True, din_max=max(self.Oa, self.Oc))
+        # the backward chain runs in units of a power of two near the row count (mava_seq_actor_loss_f32: f16 range)
+        self.grad_scale = float(2 ** math.ceil(math.log2(self.T * self.Rm)))
         n_slab = max(1, min(NUM_CU, (self.T * self.Rm) // 32))
         self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
@@ -320,16 +328,17 @@ class RecLearner:
                     T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), ptr(rep.action),
                     ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
                     self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
-                    ptr(ws.dy), ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
+                    self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
                 ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
             else:
                 check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
                                                 ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0],
-                                                float(s.clip_eps), float(s.ent_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st),
+                                                float(s.clip_eps), float(s.ent_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
+                                                nblk, st),
                       "mava_seq_actor_loss_f32")
             ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
             self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, self.slabs,
-                                                 self.g[: self.Pa], accumulate=acc)
+                                                 self.g[: self.Pa], accumulate=acc, grad_scale=self.grad_scale)
             # ---- critic (rec_mappo.py:244-266)
             cx = self._critic_x(rep, 0, T)
             if self.critic_agg:  # E-row sequences: kernel view (E envs x 1 "agent"), A agent slots per row in the loss
@@ -339,11 +348,12 @@ class RecLearner:
             self.critic_network.forward_sequence(pc, ws, cx, c_share, c_done, rep.h0_critic, False, idx, T, c_Rm, E, c_A,
                                                  training=True)
             check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
-                                             float(s.clip_eps), float(s.vf_coef), ptr(ws.dy), ptr(ws.loss_partials), nblk, st),
+                                             float(s.clip_eps), float(s.vf_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
+                                             nblk, st),
                   "mava_seq_critic_loss_f32")
             ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
             self.critic_network.backward_sequence(pc, ws, cx, c_share, c_done, idx, T, c_Rm, E, c_A, self.slabs,
-                                                  self.g[self.Pa : self.P], accumulate=acc)
+                                                  self.g[self.Pa : self.P], accumulate=acc, grad_scale=self.grad_scale)
         parallel.allreduce_sum_(self.g)
         ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),

@@ -40,9 +40,12 @@ def rec_segments(din: int, n_out: int):
 class RecWorkspace:
     """Activation buffers (T32) for one sequence batch of `rows` = T*Rm row-steps; shared by actor and critic."""
 
-    def __init__(self, rows: int, n_out_max: int, device, training: bool = True):
+    def __init__(self, rows: int, n_out_max: int, device, training: bool = True, din_max: int = 0):
         f = lambda n: torch.empty(rows * n, device=device)
         self.rows = rows
+        # f16x2 arithmetic: the minibatch's gathered observations as a T32 matrix (features padded to 32), written once
+        # per forward pass and read by the pre-torso product and its weight-gradient product
+        self.xin = f(-(-din_max // 32) * 32) if (training and din_max > 0) else None
         self.xpre, self.gi, self.hs, self.post, self.y = f(H), f(G3), f(H), f(H), f(n_out_max)
         if training:
             self.hprev, self.saved = f(H), f(4 * H)
@@ -168,12 +171,21 @@ class _RecurrentNet:
         # pre-torso: inputs wider than 384 are consumed in column blocks (accumulating products; the weight
         # slice of one block stays register-resident), the ReLU rides on the last block
         din, Wpre = self.din, self.seg(flat, "Wpre")
+        t32_in = training and ws.xin is not None and L.mava_ppo_get_matmul_mode() == 1
+        kp = -(-din // 32) * 32
+        if t32_in:
+            launch("rec_gather", L.mava_rec_gather_t32_f32, ptr(x_ext), ptr(idx), Rm, E, A, x_share, din, din, rows, kp, ptr(ws.xin), s)
         k0 = 0
         while k0 < din:
             kc = min(384, din - k0)
             last = k0 + kc >= din
-            launch("rec_dense(pre)", L.mava_rec_dense_f32, x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din, int(k0 > 0),
-                   Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows, int(last), s)
+            if t32_in:  # column block k0 of a T32 tile starts k0 * 32 floats into the tile
+                launch("rec_dense(pre)", L.mava_rec_dense_f32, ws.xin.data_ptr() + 4 * 32 * k0, 0, None, 0, 0, 0, 1, kp, int(k0 > 0),
+                       Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows, int(last), s)
+            else:
+                launch("rec_dense(pre)", L.mava_rec_dense_f32, x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din,
+                       int(k0 > 0), Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows,
+                       int(last), s)
             k0 += kc
         launch("rec_dense(gi)", L.mava_rec_dense_f32, ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H,
                G3, rows, 0, s)
@@ -187,8 +199,9 @@ class _RecurrentNet:
         return y
 
     def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
-                          accumulate: bool) -> None:
-        """BPTT from ws.dy (T32 d loss / d outputs) to the flat gradient `grad_out` (same layout as `flat`)."""
+                          accumulate: bool, grad_scale: float = 1.0) -> None:
+        """BPTT from ws.dy (T32 d loss / d outputs, in units of `grad_scale`: a power of two, see
+        mava_seq_actor_loss_f32) to the flat gradient `grad_out` (same layout as `flat`, true units)."""
         rows = T * Rm
         L = lib()
         s = stream_ptr()
@@ -209,7 +222,7 @@ class _RecurrentNet:
         def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
             """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
             launch("rec_xty", L.mava_rec_xty_f32, x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), K, N,
-                   rows, 1, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
+                   rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
             ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
             if b_off is not None:
                 tail = slabs[:, K * N + bias_slice : K * N + bias_slice + nb].contiguous()
@@ -220,11 +233,16 @@ class _RecurrentNet:
         xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
         xty(ptr(ws.xpre), 0, H, H, G3, ws.dgi, o("Wi"), o("bi"), G3)
         xty(ptr(ws.hprev), 0, H, H, G3, ws.dgh, o("Wh"), o("bhn"), H, bias_slice=2 * H)  # db_hn: n-part of colsum(dgh)
+        t32_in = ws.xin is not None and L.mava_ppo_get_matmul_mode() == 1  # the forward pass left the gathered input in ws.xin
+        kp = -(-self.din // 32) * 32
         k0 = 0
         while k0 < self.din:  # column blocks of wide inputs (each block's rows of W_pre are contiguous)
             kc = min(384, self.din - k0)
-            xty(x_ext.data_ptr() + 4 * k0, 1, self.din, kc, H, ws.dxpre, o("Wpre") + k0 * H, o("bpre") if k0 == 0 else None, H,
-                xs=x_share)
+            if t32_in:
+                xty(ws.xin.data_ptr() + 4 * 32 * k0, 0, kp, kc, H, ws.dxpre, o("Wpre") + k0 * H, o("bpre") if k0 == 0 else None, H)
+            else:
+                xty(x_ext.data_ptr() + 4 * k0, 1, self.din, kc, H, ws.dxpre, o("Wpre") + k0 * H, o("bpre") if k0 == 0 else None, H,
+                    xs=x_share)
             k0 += kc
 
 

@@ -26,9 +26,20 @@ def _from_t32(flat, rows, N):
     return np.asarray(flat).reshape(rows // 32, N, 32).transpose(0, 2, 1).reshape(rows, N)
 
 
+@pytest.fixture(params=[0, 1], ids=["f32", "f16x2"])
+def rec_mode(request):
+    """Arithmetic of the dense / X^T Y products on T32 operands: 0 exact-f32 MFMAs, 1 split-f16 operands
+    (rec_dense_h2.hip; three f16 MFMAs per product, f32 accumulation)."""
+    from mava_amd._lib import lib
+
+    lib().mava_ppo_set_matmul_mode(request.param)
+    yield request.param
+    lib().mava_ppo_set_matmul_mode(0)
+
+
 @pytest.mark.parametrize("K,N,relu,gated", [(128, 384, False, False), (128, 128, True, False), (128, 13, False, False),
                                              (384, 128, False, True), (5, 128, False, True), (192, 128, True, False), (128, 256, False, False)])
-def test_rec_dense_t32(dev, K, N, relu, gated):
+def test_rec_dense_t32(dev, K, N, relu, gated, rec_mode):
     from mava_amd._lib import check, lib, ptr, stream_ptr
 
     rng = np.random.default_rng(K + N)
@@ -51,7 +62,7 @@ def test_rec_dense_t32(dev, K, N, relu, gated):
 
 
 @pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
-def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant):
+def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd import ops
 
@@ -84,7 +95,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant):
     dy = rng.standard_normal((rows, N)).astype(np.float32)
     dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), K, N, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), K, N, rows, 1, 1.0,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -95,11 +106,32 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant):
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
     x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 128, 384, rows, 1,
+    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 128, 384, rows, 1, 0.25,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
-    assert_close(out.cpu().numpy()[: 128 * 384].reshape(128, 384), x2.astype(np.float64).T @ dy2.astype(np.float64), 1e-5, "xty t32")
+    assert_close(out.cpu().numpy()[: 128 * 384].reshape(128, 384), 0.25 * x2.astype(np.float64).T @ dy2.astype(np.float64), 1e-5,
+                 "xty t32 (out_scale 0.25)")
+    assert_close(out.cpu().numpy()[128 * 384 :], 0.25 * dy2.astype(np.float64).sum(0), 1e-5, "xty t32 db")
+    # the gathered observations as a padded T32 matrix (mava_rec_gather_t32_f32), then both products on T32 operands:
+    # the path the f16x2 arithmetic takes (exact copies in either mode)
+    for src_d, share, xs in ((obs_d, 1, xg), (gs_d, A, np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64))):
+        kp = -(-K // 32) * 32
+        xin = torch.full((rows * kp,), 7.0, device=dev)
+        check(lib().mava_rec_gather_t32_f32(ptr(src_d), ptr(idx_d), Rm, E, A, share, K, K, rows, kp, ptr(xin), stream_ptr()), "gather")
+        got_x = _from_t32(xin.cpu().numpy(), rows, kp)
+        assert np.array_equal(got_x[:, :K], xs.astype(np.float32)) and not got_x[:, K:].any(), "gathered T32 input"
+        if rec_mode == 1:  # (the exact-f32 kernel reads padded T32 inputs only when K is a multiple of 16)
+            check(lib().mava_rec_dense_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, 0, ptr(w_d), N, ptr(b_d), None, ptr(y), K, N, rows, 1,
+                                           stream_ptr()), "dense on the gathered input")
+            assert_close(_from_t32(y.cpu().numpy(), rows, N), np.maximum(xs @ w.astype(np.float64) + b, 0), 1e-5,
+                         "dense, gathered T32")
+        slab = torch.zeros((5, K * N + N), device=dev)
+        check(lib().mava_rec_xty_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
+                                     stream_ptr()), "xty on the gathered input")
+        out = torch.zeros(K * N + N, device=dev)
+        ops.slab_reduce(slab, K * N + N, out)
+        assert_close(out.cpu().numpy()[: K * N].reshape(K, N), xs.T @ dy.astype(np.float64), 1e-5, "xty dW, gathered T32")
 
 
 def _seq_case(rng, T, E, A, Em, din, nA, shared):
@@ -123,7 +155,7 @@ def _gather(x, idx, A, shared):
 # 155, 13 actions, seq_len = 128 (f32 error growth over 128 GRU steps against the float64 oracle)
 @pytest.mark.parametrize("shared,T,E,A,Em,din,nA", [(False, 9, 12, 4, 8, 37, 6), (True, 9, 12, 4, 8, 37, 6),
                                                     (False, 128, 8, 8, 4, 155, 13), (True, 128, 8, 8, 4, 188, 1)])
-def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA):
+def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA, rec_mode):
     from mava_amd.networks import DiscreteActionHead, MLPTorso
     from mava_amd.rec_networks import RecurrentActor, RecWorkspace, t32_to_rows
 
@@ -135,7 +167,7 @@ def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA):
     flat[net.off["bhn"][0] : net.off["bhn"][0] + 128] = rng.standard_normal(128) * 0.1
     assert flat.size == net.num_params == ro.rec_param_count(din, nA)
     Rm = Em * A
-    ws = RecWorkspace(T * Rm, nA, dev)
+    ws = RecWorkspace(T * Rm, nA, dev, din_max=din)
     flat_d, obs_d, done_d, h0_d, idx_d = _t(flat, dev), _t(obs, dev), _t(done, dev).view(torch.uint8), _t(h0, dev), _t(idx, dev)
     y = net.forward_sequence(flat_d, ws, obs_d, A if shared else 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
     torch.cuda.synchronize()
@@ -162,7 +194,9 @@ def xty_variant(request):
 # (128, 8, 8, 4, 155, 13): BPTT over the FULL sequence length of BASELINE config 4 (seq_len = 128, 8 agents, input 155,
 # 13 actions) - actor and critic gradients at the north-star 1e-4 against float64 autograd
 @pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13), (128, 8, 8, 4, 155, 13)])
-def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant):
+def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant, rec_mode):
+    if xty_variant == 1 and rec_mode == 1:
+        pytest.skip("the bf16x6 X^T Y variant is an alternative to the f16x2 arithmetic, not a combination")
     from mava_amd import ops
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd.networks import DiscreteActionHead, MLPTorso
@@ -192,7 +226,8 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_varia
     old_v[:, idx] = (v_now[..., 0] + rng.standard_normal(lp_now.shape) * 0.2).reshape(T, Em, A)
     tgt[:, idx] = (v_now[..., 0] + rng.standard_normal(lp_now.shape)).reshape(T, Em, A)
 
-    ws = RecWorkspace(rows, max(nA, 1), dev)
+    ws = RecWorkspace(rows, max(nA, 1), dev, din_max=din)
+    gscale = float(2 ** int(np.ceil(np.log2(rows))))  # the backward chain runs in these units (RecLearner.grad_scale)
     d = lambda a, dt=None: _t(a, dev, dt)
     idx_d, done_d, h0_d, obs_d = d(idx), d(done).view(torch.uint8), d(h0), d(obs)
     slabs = torch.zeros((4, 128 * 384 + 384 + 8), device=dev)
@@ -203,10 +238,10 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_varia
     adv_d, mask_d, act_d, olp_d = d(adv), d(mask).view(torch.uint8), d(action), d(old_lp)  # kept alive (see above)
     stats = ops.adv_stats(adv_d.view(-1), flat_rows, 0, T * Em, A)
     check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(mask_d), ptr(act_d),
-                                        ptr(olp_d), ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, ptr(ws.dy),
+                                        ptr(olp_d), ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, gscale, ptr(ws.dy),
                                         ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "actor loss")
     ga = torch.zeros(actor.num_params, device=dev)
-    actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False)
+    actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False, grad_scale=gscale)
     torch.cuda.synchronize()
     tot, la, ent, g = ro.rec_actor_loss_grad(fa, din, nA, go(obs), go(done), go(h0[None])[0], go(mask), go(action), go(old_lp),
                                              go(adv), 0.2, 0.01)
@@ -221,18 +256,19 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_varia
     fc_d = d(fc)
     critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
     ov_d, tg_d = d(old_v), d(tgt)
-    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, 1, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, ptr(ws.dy),
+    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, 1, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, gscale, ptr(ws.dy),
                                          ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
     gc = torch.zeros(critic.num_params, device=dev)
-    critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False)
+    critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False, grad_scale=gscale)
     torch.cuda.synchronize()
     tot, vl, g = ro.rec_critic_loss_grad(fc, din, go(obs), go(done), go(h0[None])[0], go(old_v), go(tgt), 0.2, 0.5)
     assert_close(ws.loss_partials.sum(0).cpu().numpy()[:1], np.array([vl]), 1e-5, "value loss", scale=1.0)
     assert_close(gc.cpu().numpy(), g, 1e-4, "recurrent critic gradient")
 
 
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
 @pytest.mark.parametrize("system,U,E", [("rec_mappo", 1, 16), ("rec_ippo", 2, 16), ("rec_mappo", 1, 64)])
-def test_rec_learner_update_matches_oracle(dev, system, U, E):
+def test_rec_learner_update_matches_oracle(dev, system, U, E, matmul):
     """End to end: the HIP recurrent learner against the whole-update oracle on identical inputs.  E = 64 switches the
     centralised critic to one sequence per ENV (the agents share the global state; the oracle, like the reference,
     evaluates all E*A tiled rows)."""
@@ -250,6 +286,7 @@ def test_rec_learner_update_matches_oracle(dev, system, U, E):
     cfg.env.kwargs.time_limit = 4  # forces resets inside the rollout (hidden-state resets, GAE masking)
     cfg.system.num_updates_per_eval = 2
     cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    cfg.system.matmul_mode = matmul
     central = system == "rec_mappo"
     mod = rec_mappo if central else rec_ippo
     env, _ = envs.make(cfg, add_global_state=central, device=dev)
@@ -287,8 +324,11 @@ def test_rec_learner_update_matches_oracle(dev, system, U, E):
         assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
         assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
         assert_close(L.p[L.Pa :].cpu().numpy() - fc, ora.pc - fc, 2e-3, "critic update")
-        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
-        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        # f16x2: ~22-bit operands; Adam's 1 / (sqrt(v) + eps) amplifies the error of entries whose gradient is tiny
+        # (same bounds as tests/test_gpu_learner.py)
+        ptol = 1e-5 if matmul == "f32" else 1e-4
+        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, ptol, "actor params")
+        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, ptol, "critic params")
     out = learn(L.learner_state())
     torch.cuda.synchronize()
     assert out.train_metrics["total_loss"].shape == (1, 2, U, K, M) and torch.isfinite(out.train_metrics["total_loss"]).all()

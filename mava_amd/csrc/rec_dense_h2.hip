@@ -3,39 +3,81 @@
 //
 // Every f32 operand is split into two f16 terms (hi + lo, ~22 bits) where it enters a matrix product and the product
 // is three v_mfma_f32_32x32x16_f16 (lo*hi + hi*lo + hi*hi, f32 accumulation): 96 instead of 512 matrix-pipe cycles per
-// 16 inputs.  Both kernels read their T32 operands STRAIGHT from memory in MFMA operand layout - no LDS, no barriers:
-//  * dense:  lane (row j, half h) of a 16-input batch reads features 16b + 2e + h, e = 0..7 (eight coalesced
-//    128-byte accesses per wave-half), exactly the accesses of the f32 kernel; the weight slice of a wave is split
-//    once per launch (error diffusion along the summation index) and stays in registers.
-//  * X^T Y:  the product sums over batch rows, and a T32 tile holds the 32 rows of a feature contiguously: lane
-//    (feature j, half h) reads rows 16s + 8h .. + 7 as two 16-byte loads - the operand fragment of k-step s.
-// Backward operands (loss gradients) are O(1/rows): the caller runs the backward chain in units scaled by a power of
-// two (mava_seq_*_loss_f32 grad_scale) so that they sit in f16's normal range, and the X^T Y epilogue multiplies the
-// inverse back in (XtyTask::out_scale); powers of two are exact in f32, so the f32 kernels are unaffected.
+// 16 inputs - at that rate both kernels are HBM-bound, and they are built as streaming kernels:
+//  * a T32 tile (32 rows) is ONE contiguous run of K*32 floats: the block reads it with 16-byte loads, each byte once
+//    per CU, a full tile ahead (the loads of tile i+2 are issued while tile i is multiplied);
+//  * the loading thread splits its four values once and stores them as f16 hi / lo planes in LDS, [feature][32 rows]
+//    (64 bytes per feature, 16-byte chunks XOR-swizzled by the feature index so that neither access below conflicts);
+//  * X^T Y sums over batch rows: an operand fragment (8 consecutive rows of a feature) is one ds_read_b128 per plane;
+//    the dense layer sums over features: its fragment (8 consecutive features of a row) comes from the same layout
+//    through the hardware-transposed ds_read_b64_tr_b16 - one staging format serves both;
+//  * LDS is double-buffered: the commit of tile i+1 is sliced between the MFMA groups of tile i (VALU and LDS writes
+//    run under the matrix pipe) and a tile costs one block barrier.
+// The weight slice of a dense wave is split once per launch (error diffusion along the summation index) and stays in
+// registers.  Backward operands (loss gradients) are O(1/rows): the caller runs the backward chain in units scaled by a
+// power of two (mava_seq_*_loss_f32 grad_scale) so that they sit in f16's normal range, and the X^T Y epilogue
+// multiplies the inverse back in (XtyTask::out_scale); powers of two are exact in f32.
 // mava_rec_gather_t32_f32 turns the row-major, env-permuted observation slice of a minibatch into a T32 matrix once
-// per minibatch (features padded to a multiple of 16 with zeros), which the pre-torso product AND its weight-gradient
+// per minibatch (features padded to a multiple of 32 with zeros), which the pre-torso product AND its weight-gradient
 // product then read as plain T32 operands.
+#include <float.h>
+
 #include "h2_core.h"
 #include "rec_task.h"
 
 namespace {
 
 using h2::Frag;
+using h2::half4;
 using h2::half8;
+using h2::u8;
+using h2::s16x4;
 
 #define DOFF(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
 
-// NB = 16-input batches of K, NTW = 32-feature output tiles per wave (tiles w, w+4, w+8).
-// FULLK: the x tiles hold exactly 16*NB features (compile-time operand offsets); else (NB <= 2) clamped loads.
-template <int NB, int NTW, bool FULLK>
-__global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
-  const int K = tk.K, N = tk.N;
-  const int KX = tk.x_ld;  // features per x tile (>= 16 NB when FULLK)
-  const int ntile_n = (N + 31) / 32;
+// ---- staging: float4 number q of a T32 tile = rows 4 (q & 7) .. + 3 of feature q >> 3 -> 8 bytes in each plane
+__device__ __forceinline__ int stage_off(int q) {
+  const int f = q >> 3, c = (q & 7) >> 1;
+  return f * 64 + ((c ^ ((f >> 2) & 3)) << 4) + 8 * (q & 1);
+}
+__device__ __forceinline__ void stage4(u8* plane_hi, int plane_bytes, int off, const float4& v) {
+  half4 ph, pl;
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 a, b;
+    h2::split1(vv[e], a, b);
+    ph[e] = a;
+    pl[e] = b;
+  }
+  *reinterpret_cast<half4*>(plane_hi + off) = ph;
+  *reinterpret_cast<half4*>(plane_hi + plane_bytes + off) = pl;
+}
+// rows 8c .. 8c + 7 of feature f (the fragment of a product that sums over batch rows)
+__device__ __forceinline__ Frag rows_frag(const u8* plane_hi, int plane_bytes, int f, int c) {
+  const int off = f * 64 + ((c ^ ((f >> 2) & 3)) << 4);
+  Frag r;
+  r.hi = *reinterpret_cast<const half8*>(plane_hi + off);
+  r.lo = *reinterpret_cast<const half8*>(plane_hi + plane_bytes + off);
+  return r;
+}
 
-  // ---- resident weight slice, split once: wf[tw][b] element e = W[16b + 2e + h][32(w + 4tw) + j]
+// Y = act(X W + b) [gated] for T32 X (x_ld features per tile, the first K used).
+// NB = 16-input batches of K, NTW = 32-feature output tiles per wave (tiles w, w+4, w+8).
+template <int NB, int NTW>
+__global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
+  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+  constexpr int XF = 16 * NB;          // staged features
+  constexpr int XPL = XF * 64;         // bytes per plane
+  constexpr int BUF = 2 * XPL;         // hi, lo
+  constexpr int XS = (XF * 8 + 255) / 256;  // float4 slots per thread and tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, h = lane >> 5, j = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches
+  const int K = tk.K, N = tk.N;
+  const int nx4 = K * 8;
+
+  // ---- resident weight slice, split once: wf[tw][b] element e = W[16b + 8h + e][32(w + 4tw) + j]
   Frag wf[NTW][NB];
   {
     float wreg[NTW][NB][8];
@@ -47,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = 16 * b + 2 * e + h;
+          const int k = 16 * b + 8 * h + e;
           const int kc = k < K ? k : (K - 1);
           wreg[tw][b][e] = tk.w[(long)kc * tk.ldw + colc];
         }
@@ -60,33 +102,100 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = 16 * b + 2 * e + h;
+          const int k = 16 * b + 8 * h + e;
           wreg[tw][b][e] = (k < K && col < N) ? wreg[tw][b][e] : 0.0f;
         }
         wf[tw][b] = h2::split8_carry(wreg[tw][b], carry);
       }
     }
   }
+  // features past K are never staged: they must read as zeros (their weights are zero, 0 * garbage may be NaN)
+  for (int i = tid; i < 2 * BUF / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float breg[NTW][16];
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * (w + 4 * tw) + 4 * h + (r & 3) + 8 * (r >> 2);
+      breg[tw][r] = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
+    }
 
   const int ntiles = tk.rows / 32;
+  // transposed operand reads: lane (row j, half h) receives features 16b + 8h + 0..7 of row j from two 4-feature blocks
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, g1 = (lane >> 4) & 1;
+  const int chunk = 2 * g1 + (tp >> 1), o8 = 8 * (tp & 1);
+  const int tr0 = (8 * h + tq) * 64 + ((chunk ^ (2 * h)) << 4) + o8;            // + 1024 b
+  const int tr1 = (8 * h + tq + 4) * 64 + ((chunk ^ (2 * h + 1)) << 4) + o8;
+  auto x_frag = [&](const u8* buf, int b) {
+    Frag f;
+    const u8* p0 = buf + tr0 + 1024 * b;
+    const u8* p1 = buf + tr1 + 1024 * b;
+    const h2::s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p0));
+    const h2::s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p1));
+    const h2::s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p0 + XPL));
+    const h2::s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p1 + XPL));
+    f.hi = __builtin_bit_cast(half8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+    f.lo = __builtin_bit_cast(half8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
+    return f;
+  };
+
+  float4 raw[XS];
+  int soff[XS];
+#pragma unroll
+  for (int k = 0; k < XS; ++k) soff[k] = stage_off(tid + 256 * k);
+  auto issue = [&](int it, int k) {
+    const float4* xs = reinterpret_cast<const float4*>(tk.x + (long)it * tk.x_ld * 32);
+    const int q = tid + 256 * k;
+    raw[k] = xs[q < nx4 ? q : (nx4 - 1)];
+  };
+  // branch-free: a slot past the K used features stages zeros (its loads are clamped duplicates)
+  auto commit = [&](u8* buf, int k) {
+    const bool in = tid + 256 * k < nx4;
+    float4 v = raw[k];
+    v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+    // an odd NB stages 128 NB float4: the upper half of the block has no feature row in the last slot
+    if (!(NB & 1) || k < XS - 1 || tid < 128) stage4(buf, XPL, soff[k], v);
+  };
+  // Output tile: activation, optional relu-mask gate, coalesced T32 stores.  A wave whose 32 features all exist takes a
+  // straight-line path (wave-uniform scalar branches only): per-element bounds checks and pointer tests cost a tile more
+  // issue slots than its matrix products.
   auto epilogue = [&](int it, f32x16 (&acc)[NTW], const float (&gpre)[16], bool use_pre) {
+    const float floor_v = tk.relu ? 0.0f : -FLT_MAX;
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
       const long base = ((long)it * N + fb) * 32 + j;
       float* const yo = tk.y + base;
       const float* const go = tk.gate != nullptr ? tk.gate + base : nullptr;
+      if (32 * (w + 4 * tw) + 32 <= N) {
+        if (go == nullptr) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = fb + (r & 3) + 8 * (r >> 2);
-        if (f < N) {
-          float v = acc[tw][r];
-          if (tk.relu) v = fmaxf(v, 0.0f);
-          if (go != nullptr) {
-            const float gv = (use_pre && tw == 0) ? gpre[r] : go[DOFF(r)];
-            v = (gv > 0.0f) ? v : 0.0f;
+          for (int r = 0; r < 16; ++r) yo[DOFF(r)] = fmaxf(acc[tw][r], floor_v);
+        } else {
+          float gv[16];
+          if (use_pre && tw == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[r] = gpre[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[r] = go[DOFF(r)];
           }
-          yo[DOFF(r)] = v;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yo[DOFF(r)] = (gv[r] > 0.0f) ? fmaxf(acc[tw][r], floor_v) : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = fb + (r & 3) + 8 * (r >> 2);
+          if (f < N) {
+            float v = fmaxf(acc[tw][r], floor_v);
+            if (go != nullptr) {
+              const float gv = (use_pre && tw == 0) ? gpre[r] : go[DOFF(r)];
+              v = (gv > 0.0f) ? v : 0.0f;
+            }
+            yo[DOFF(r)] = v;
+          }
         }
       }
     }
@@ -97,137 +206,87 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = go[(fb + (r & 3) + 8 * (r >> 2) < N) ? DOFF(r) : 0];
   };
-  // the bias stays in registers for the whole launch: a per-tile reload sits in front of the tile's first MFMA, and
-  // with in-order memory returns it also waits for the whole operand prefetch ring
-  float breg[NTW][16];
-#pragma unroll
-  for (int tw = 0; tw < NTW; ++tw)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * (w + 4 * tw) + 4 * h + (r & 3) + 8 * (r >> 2);
-      breg[tw][r] = (tk.bias != nullptr && f < N) ? tk.bias[f] : 0.0f;
-    }
-  auto init_acc = [&](int it, f32x16 (&acc)[NTW]) {
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw) {
-      const int fb = 32 * (w + 4 * tw) + 4 * h;
-      const float* const yo = tk.y + ((long)it * N + fb) * 32 + j;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = fb + (r & 3) + 8 * (r >> 2);
-        float a0 = breg[tw][r];
-        if (tk.accumulate && f < N) a0 += yo[DOFF(r)];
-        acc[tw][r] = a0;
-      }
-    }
-  };
-  auto tile_ptr = [&](int it) { return tk.x + ((long)it * KX + (FULLK ? h : 0)) * 32 + j; };
-  auto load_batch = [&](const float* xp, int bq, float (&dst)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (FULLK) {
-        dst[e] = xp[(16 * bq + 2 * e) * 32];  // elem(row j, k + h): h folded into the tile pointer
-      } else {
-        int k = 16 * bq + 2 * e + h;
-        k = k < KX ? k : (KX - 1);  // weights past K are zero
-        dst[e] = xp[(long)k * 32];
-      }
-    }
-  };
   const bool pf_gate = (NTW == 1) && tk.gate != nullptr && (32 * w < N);
 
-  if (NB <= 2) {
-    // narrow inputs (the n_out-wide loss gradient of the head backward): a tile is 3 NB MFMAs, far shorter than a
-    // memory round trip - the whole x tile and the gate values run PF tiles ahead through rotating registers
-    constexpr int PF = 3;
-    float xq[PF + 1][NB][8], gq[PF + 1][16];
-    int it = blockIdx.x;
-#pragma unroll
-    for (int d = 1; d <= PF; ++d) {
-      const int itd = it + (d - 1) * (int)gridDim.x;
-      const int itc = itd < ntiles ? itd : (ntiles - 1);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) load_batch(tile_ptr(itc), b, xq[d][b]);
-      if (pf_gate) load_gate(itc, gq[d]);
-    }
-    for (; it < ntiles; it += gridDim.x) {
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xq[d][b][e] = xq[d + 1][b][e];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gq[d][r] = gq[d + 1][r];
-      }
-      {
-        const int itd = it + PF * (int)gridDim.x;
-        const int itc = itd < ntiles ? itd : (ntiles - 1);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) load_batch(tile_ptr(itc), b, xq[PF][b]);
-        if (pf_gate) load_gate(itc, gq[PF]);
-      }
-      f32x16 acc[NTW];
-      init_acc(it, acc);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const Frag xf = h2::split8(xq[0][b]);
-#pragma unroll
-        for (int tw = 0; tw < NTW; ++tw)
-          acc[tw] = h2::mfma3(wf[tw][b], xf, acc[tw]);  // n-tiles past N run on clamped operands and are never stored
-      }
-      epilogue(it, acc, gq[0], pf_gate);
-    }
-    return;
-  }
-
-  // ---- operand batches stream through a ring that runs ACROSS row tiles (prefetch distance RDX - 1 batches)
-  constexpr int RDX = (NB <= 2) ? 1 : (NB % 8 == 0) ? 8 : ((NB % 6 == 0) ? 6 : ((NB % 5 == 0) ? 5 : ((NB % 4 == 0) ? 4 : 2)));
-  constexpr int PD = RDX > 1 ? RDX - 1 : 0;
-  static_assert(NB % RDX == 0, "ring depth must divide the batch count");
-  float xo[RDX][8];
-  float gcur[16], gnext[16];
+  const int G = gridDim.x;
   int it = blockIdx.x;
-  const float* xt_cur = tile_ptr(it < ntiles ? it : 0);
+  __syncthreads();  // zero fill done
+  if (it < ntiles) {
 #pragma unroll
-  for (int d = 0; d < PD; ++d) load_batch(xt_cur, d % NB, xo[d]);
+    for (int k = 0; k < XS; ++k) issue(it, k);
+#pragma unroll
+    for (int k = 0; k < XS; ++k) commit(lds, k);
+  }
+  {
+    const int itn = it + G;
+#pragma unroll
+    for (int k = 0; k < XS; ++k) issue(itn < ntiles ? itn : (ntiles - 1), k);
+  }
+  float gcur[16], gnext[16];
   if (pf_gate && it < ntiles) load_gate(it, gnext);
-  for (; it < ntiles; it += gridDim.x) {
-    const int itn = it + gridDim.x;
-    const float* xt_next = (itn < ntiles) ? tile_ptr(itn) : xt_cur;
+  __syncthreads();
+  int cur = 0;
+  for (; it < ntiles; it += G) {
+    const u8* const rb = lds + cur * BUF;
+    u8* const wbuf = lds + (cur ^ 1) * BUF;
+    const int itn = it + G, itnn = it + 2 * G;
+    const bool has_next = itn < ntiles;
+    const int it_issue = itnn < ntiles ? itnn : (ntiles - 1);
     if (pf_gate) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) gcur[r] = gnext[r];
-      load_gate(itn < ntiles ? itn : it, gnext);
+      load_gate(has_next ? itn : it, gnext);
     }
     f32x16 acc[NTW];
-    init_acc(it, acc);
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tw][r] = breg[tw][r];
+    if (tk.accumulate) {  // K-chunked products (inputs wider than 384): start from the existing output
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw) {
+        const int fb = 32 * (w + 4 * tw) + 4 * h;
+        const float* const yo = tk.y + ((long)it * N + fb) * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (fb + (r & 3) + 8 * (r >> 2) < N) acc[tw][r] += yo[DOFF(r)];
+      }
+    }
+    Frag xf[2];
+    xf[0] = x_frag(rb, 0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      {
-        const int bq = b + PD;
-        if (bq < NB) load_batch(xt_cur, bq, xo[bq % RDX]);
-        else load_batch(xt_next, bq - NB, xo[bq % RDX]);
-      }
-      const Frag xf = h2::split8(xo[b % RDX]);
+      if (b + 1 < NB) xf[(b + 1) & 1] = x_frag(rb, b + 1);
 #pragma unroll
-      for (int tw = 0; tw < NTW; ++tw)
-        acc[tw] = h2::mfma3(wf[tw][b], xf, acc[tw]);
+      for (int tw = 0; tw < NTW; ++tw) acc[tw] = h2::mfma3(wf[tw][b], xf[b & 1], acc[tw]);  // tiles past N: never stored
+      // this batch's share of the next tile's commit, and the loads of the tile after it into the freed registers
+#pragma unroll
+      for (int k = (b * XS) / NB; k < ((b + 1) * XS) / NB; ++k) {
+        commit(wbuf, k);  // (after the last tile: a duplicate nobody reads)
+        issue(it_issue, k);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     epilogue(it, acc, gcur, pf_gate);
-    xt_cur = xt_next;
+    __syncthreads();
+    cur ^= 1;
   }
 }
 
-// dW = X^T Y, db = colsum(Y) for T32 X (KX features per tile, the first K used) and T32 Y.
+// dW = X^T Y, db = colsum(Y) for T32 X (x_ld features per tile, the first K used) and T32 Y.
 // KT = 32-feature tiles of X (accumulator rows), NTW = 32-feature tiles of Y per wave (tiles w, w+4, w+8).
 template <int KT, int NTW>
 __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
+  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+  constexpr int NT = 4 * NTW;
+  constexpr int XPL = 32 * KT * 64, YPL = 32 * NT * 64;  // bytes per plane
+  constexpr int BUF = 2 * XPL + 2 * YPL;                 // X hi, X lo, Y hi, Y lo
+  constexpr int S = KT + NT;                             // float4 slots per thread and tile: X then Y
+  constexpr int NG = 2 * NTW;                            // MFMA groups per tile: (k-step s, y tile tw)
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
-  const int K = tk.K, N = tk.N, KX = tk.x_ld;
-  const int ntile_n = (N + 31) / 32;
+  const int K = tk.K, N = tk.N;
+  const int nx4 = K * 8, ny4 = N * 8;
 
   f32x16 acc[KT][NTW];
 #pragma unroll
@@ -236,78 +295,80 @@ __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
     for (int tw = 0; tw < NTW; ++tw)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[kt][tw][r] = 0.0f;
-  float bsum[NTW];
+  float bacc[NT];  // lanes with (tid & 7) == 0: column sum of y feature (tid >> 3) + 32 i
 #pragma unroll
-  for (int tw = 0; tw < NTW; ++tw) bsum[tw] = 0.0f;
+  for (int i = 0; i < NT; ++i) bacc[i] = 0.0f;
 
-  // per-lane float4 offsets inside a tile: feature (clamped to the matrix), rows 8h .. 8h + 7 of k-step 0
-  int xoff[KT], yoff[NTW];
+  float4 raw[S];
+  int soff[S];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    const int f = 32 * kt + j;
-    xoff[kt] = ((f < KX ? f : (KX - 1)) * 32 + 8 * h) / 4;
-  }
-#pragma unroll
-  for (int tw = 0; tw < NTW; ++tw) {
-    const int f = 32 * (w + 4 * tw) + j;
-    yoff[tw] = ((f < N ? f : (N - 1)) * 32 + 8 * h) / 4;
-  }
-  // raw operands of one tile: [k-step s][feature tile][2 x float4]
-  float4 xr[2][KT][2], yr[2][NTW][2];
-  auto issue = [&](int it, float4 (&xd)[2][KT][2], float4 (&yd)[2][NTW][2]) {
-    const float4* xs = reinterpret_cast<const float4*>(tk.x + (long)it * KX * 32);
-    const float4* ys = reinterpret_cast<const float4*>(tk.y + (long)it * N * 32);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        xd[s][kt][0] = xs[xoff[kt] + 4 * s];
-        xd[s][kt][1] = xs[xoff[kt] + 4 * s + 1];
-      }
-#pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
-        yd[s][tw][0] = ys[yoff[tw] + 4 * s];
-        yd[s][tw][1] = ys[yoff[tw] + 4 * s + 1];
-      }
+  for (int k = 0; k < S; ++k) soff[k] = stage_off(tid + 256 * (k < KT ? k : k - KT));
+  auto issue = [&](int it, int k) {
+    if (k < KT) {
+      const float4* xs = reinterpret_cast<const float4*>(tk.x + (long)it * tk.x_ld * 32);
+      const int q = tid + 256 * k;
+      raw[k] = xs[q < nx4 ? q : (nx4 - 1)];
+    } else {
+      const float4* ys = reinterpret_cast<const float4*>(tk.y + (long)it * N * 32);
+      const int q = tid + 256 * (k - KT);
+      raw[k] = ys[q < ny4 ? q : (ny4 - 1)];
     }
   };
-  auto to8 = [](const float4& a, const float4& b, float (&v)[8]) {
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  // Branch-free: slots past K / N stage clamped duplicates into feature rows whose products are never stored.
+  // `live` is 1.0f for a real tile, 0.0f for the duplicate committed after a block's last tile.
+  auto commit = [&](u8* buf, int k, float live) {
+    if (k < KT) {
+      stage4(buf, XPL, soff[k], raw[k]);
+    } else {
+      stage4(buf + 2 * XPL, YPL, soff[k], raw[k]);
+      // this thread's four rows of its feature; the 8 threads of a feature are added up once, after the last tile
+      bacc[k - KT] += live * ((raw[k].x + raw[k].y) + (raw[k].z + raw[k].w));
+    }
   };
 
   const int ntiles = tk.rows / 32;
+  const int G = gridDim.x;
   int it = blockIdx.x;
-  if (it < ntiles) issue(it, xr, yr);
-  for (; it < ntiles; it += gridDim.x) {
-    const int itn = it + gridDim.x;
-    // this tile's operands leave the landing registers as split fragments (X) / a raw copy (Y) before the next tile's
-    // loads are issued into them
-    Frag xf[2][KT];
-    float4 yc[2][NTW][2];
+  if (it < ntiles) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int k = 0; k < S; ++k) issue(it, k);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        float v[8];
-        to8(xr[s][kt][0], xr[s][kt][1], v);
-        xf[s][kt] = h2::split8(v);
+    for (int k = 0; k < S; ++k) commit(lds, k, 1.0f);
+  }
+  {
+    const int itn = it + G;
+#pragma unroll
+    for (int k = 0; k < S; ++k) issue(itn < ntiles ? itn : (ntiles - 1), k);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; it < ntiles; it += G) {
+    const u8* const rb = lds + cur * BUF;
+    u8* const wbuf = lds + (cur ^ 1) * BUF;
+    const int itn = it + G, itnn = it + 2 * G;
+    const float live = itn < ntiles ? 1.0f : 0.0f;
+    const int it_issue = itnn < ntiles ? itnn : (ntiles - 1);
+    Frag xf[KT];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int s = g / NTW, tw = g % NTW;
+      if (tw == 0) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) xf[kt] = rows_frag(rb, XPL, 32 * kt + j, 2 * s + h);
       }
+      const Frag yf = rows_frag(rb + 2 * XPL, YPL, 32 * (w + 4 * tw) + j, 2 * s + h);
 #pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) { yc[s][tw][0] = yr[s][tw][0]; yc[s][tw][1] = yr[s][tw][1]; }
+      for (int kt = 0; kt < KT; ++kt) acc[kt][tw] = h2::mfma3(xf[kt], yf, acc[kt][tw]);  // tiles past K / N: never stored
+      // this group's share of the next tile's commit, and the loads of the tile after it into the freed registers
+#pragma unroll
+      for (int k = (g * S) / NG; k < ((g + 1) * S) / NG; ++k) {
+        commit(wbuf, k, live);
+        issue(it_issue, k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    issue(itn < ntiles ? itn : it, xr, yr);  // in flight during the MFMAs below
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
-        float v[8];
-        to8(yc[s][tw][0], yc[s][tw][1], v);
-        if (tk.want_bias) bsum[tw] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        const Frag yf = h2::split8(v);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc[kt][tw] = h2::mfma3(xf[s][kt], yf, acc[kt][tw]);  // tiles past N: never stored
-      }
+    __syncthreads();
+    cur ^= 1;
   }
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
   const float sc = tk.out_scale;
@@ -323,10 +384,13 @@ __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
       }
   if (tk.want_bias) {
 #pragma unroll
-    for (int tw = 0; tw < NTW; ++tw) {
-      const float b = bsum[tw] + __shfl_xor(bsum[tw], 32, 64);
-      const int n = 32 * (w + 4 * tw) + j;
-      if (h == 0 && n < N) slab[(long)K * N + n] = b * sc;
+    for (int i = 0; i < NT; ++i) {
+      float b = bacc[i];
+      b += __shfl_xor(b, 1, 64);
+      b += __shfl_xor(b, 2, 64);
+      b += __shfl_xor(b, 4, 64);
+      const int n = (tid >> 3) + 32 * i;
+      if ((tid & 7) == 0 && n < N) slab[(long)K * N + n] = b * sc;
     }
   }
 }
@@ -353,18 +417,32 @@ __global__ __launch_bounds__(256) void rec_gather_t32_kernel(DenseTask tk, int K
   }
 }
 
-template <int NB, int NTW, bool FULLK>
+template <int NB, int NTW>
 int launch_dense_h2(const DenseTask& tk, hipStream_t s) {
+  constexpr int lb = 2 * 2 * 16 * NB * 64;  // two buffers of hi + lo planes
+  static bool attr_set = false;
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_h2_kernel<NB, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    attr_set = true;
+  }
   int blocks = tk.rows / 32;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL((rec_dense_h2_kernel<NB, NTW, FULLK>), dim3(blocks), dim3(256), 0, s, tk);
+  hipLaunchKernelGGL((rec_dense_h2_kernel<NB, NTW>), dim3(blocks), dim3(256), lb, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
 
 template <int KT, int NTW>
 int launch_xty_h2(const XtyTask& tk, int n_slab, hipStream_t s) {
-  hipLaunchKernelGGL((rec_xty_h2_kernel<KT, NTW>), dim3(n_slab), dim3(256), 0, s, tk);
+  constexpr int lb = 2 * 2 * 32 * (KT + 4 * NTW) * 64;
+  static_assert(lb <= 163840, "double-buffered staging must fit the CU's LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_xty_h2_kernel<KT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    attr_set = true;
+  }
+  if (n_slab > tk.rows / 32) return 1;  // every block must own a tile (its prologue stages one)
+  hipLaunchKernelGGL((rec_xty_h2_kernel<KT, NTW>), dim3(n_slab), dim3(256), lb, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
@@ -375,15 +453,11 @@ int mava_rec_dense_h2_launch(const DenseTask& tk, hipStream_t s) {
   if (tk.x_rowmajor) return 1;
   const int nb = (tk.K + 15) / 16;
   const int ntw = ((tk.N + 31) / 32 + 3) / 4;
-  if (nb <= 2 && ntw == 1) {  // x tiles of exactly tk.x_ld features, any K <= 32
-    if (nb == 1) return launch_dense_h2<1, 1, false>(tk, s);
-    return launch_dense_h2<2, 1, false>(tk, s);
-  }
-  // NB batches read 16 NB features of every x tile: the tile must hold them (weights past K are zero)
+  // only the first K features of a tile are read (x_ld >= K is checked by the caller); staged features past K are zeros
 #define DENSE_H2(NBv, NTWv) \
-  if (nb <= NBv && ntw == NTWv && tk.x_ld >= 16 * NBv) return launch_dense_h2<NBv, NTWv, true>(tk, s)
-  DENSE_H2(4, 1); DENSE_H2(6, 1); DENSE_H2(8, 1); DENSE_H2(10, 1); DENSE_H2(12, 1); DENSE_H2(18, 1); DENSE_H2(24, 1);
-  DENSE_H2(8, 3);
+  if (nb <= NBv && ntw == NTWv) return launch_dense_h2<NBv, NTWv>(tk, s)
+  DENSE_H2(1, 1); DENSE_H2(2, 1); DENSE_H2(4, 1); DENSE_H2(6, 1); DENSE_H2(8, 1); DENSE_H2(10, 1); DENSE_H2(12, 1);
+  DENSE_H2(18, 1); DENSE_H2(24, 1); DENSE_H2(8, 3);
 #undef DENSE_H2
   return 1;
 }

@@ -311,6 +311,22 @@ int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int a
                                  const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
                                  float* value, mava_stream_t s);
 
+/* The same acting step on split-f16 operands with PRE-PACKED weights (rec_step_h2.hip): mava_rec_step_pack_f32 splits
+ * one network's [Wpre | Wi | Wh | Wpost] into f16 hi / lo planes in MFMA-fragment order (mava_rec_step_pack_bytes(din)
+ * bytes); do it once per rollout, after the parameters changed.  mava_rec_step_packed_f32 takes both packs plus the
+ * arguments of mava_rec_step_f32 (action_f != NULL selects the continuous head: then action / action_mask are unused and
+ * n_actions is the action dimension); a block multiplies each weight fragment with up to three 32-row tiles.  More than
+ * 16 head outputs run the exact-f32 kernel. */
+long mava_rec_step_pack_bytes(int din);
+int mava_rec_step_pack_f32(const float* params, int din, void* pack, mava_stream_t s);
+int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float* actor_params, int actor_din,
+                             int n_actions, const float* agents_view, const uint8_t* action_mask, const uint8_t* done_a,
+                             const float* h_actor_in, float* h_actor_out, int rows_a, uint64_t seed, uint32_t step,
+                             uint32_t row_offset, int greedy, int32_t* action, float* action_f, float* log_prob,
+                             const float* critic_params, int critic_din, const float* critic_input, int critic_share,
+                             const uint8_t* done_c, int done_c_stride, const float* h_critic_in, float* h_critic_out,
+                             int rows_c, int value_broadcast, float* value, mava_stream_t s);
+
 /* T32 <-> row-major conversion of a (rows x N) matrix. */
 int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);
 

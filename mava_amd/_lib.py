@@ -73,15 +73,19 @@ _SIGNATURES = {
     "mava_rec_step_f32": [vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp,
                           i32, i32, vp, vp],
     "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
+    "mava_rec_step_pack_bytes": [i32],
+    "mava_rec_step_pack_f32": [vp, i32, vp, vp],
+    "mava_rec_step_packed_f32": [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, vp, i32, vp, i32, vp,
+                                 i32, vp, vp, i32, i32, vp, vp],
     "mava_seq_sample_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_t32_convert_f32": [vp, i32, i32, i32, vp, vp],
 }
-_RESTYPES = {"mava_last_error": C.c_char_p}
+_RESTYPES = {"mava_last_error": C.c_char_p, "mava_rec_step_pack_bytes": C.c_long}
 
 
 def declared_symbols():
     """Every symbol include/mava_hip.h declares (kept in sync by tests/test_abi.py)."""
-    return sorted(list(_SIGNATURES) + list(_RESTYPES))
+    return sorted(set(_SIGNATURES) | set(_RESTYPES))
 
 
 def lib() -> C.CDLL:

@@ -30,6 +30,7 @@ HIP_SOURCES = [
     "rec_gru.hip",
     "rec_gru_h2.hip",
     "rec_step.hip",
+    "rec_step_h2.hip",
 ]
 CPP_SOURCES = ["api.cpp"]
 

@@ -14,35 +14,13 @@
 // through [feature][row] LDS tiles (stride 33).  Blocks [0, nblk_actor) serve the actor, the rest the critic - e.g.
 // one critic sequence per ENV when the agents share the critic input - so both networks share one launch.
 #include "mlp_core.h"
+#include "rec_step_task.h"
 #include "tanh_normal.h"
 
 namespace {
 
 constexpr int LDT = 33;
 constexpr int G3 = 3 * MLP_H;
-
-struct RecNet {
-  const float* params;   // [Wpre (din,128) | bpre | Wi (128,384) | bi | Wh (128,384) | bhn | Wpost | bpost | Whead (128,no) | bhead]
-  const float* x;        // (rows_x, din) row-major; row r reads x[r / xshare]
-  const uint8_t* done;   // flag ENTERING this step (resets the hidden state): row r reads done[r * done_stride]
-  int done_stride;
-  const float* h_in;     // T32 (rows x 128)
-  float* h_out;          // T32 (rows x 128)
-  int din, no, xshare, rows;
-  // LDS carve (floats)
-  int xs, ldx, nb1, et, ht, h2t, pt, w3, yp, end;
-};
-
-struct RecStepOut {
-  const uint8_t* mask;   // (rows, no) or null
-  uint32_t seed_lo, seed_hi, step, row_offset;
-  int greedy;
-  int32_t* action;
-  float* log_prob;
-  float* value;          // (rows_c * vbroadcast)
-  int vbroadcast;
-  float* action_f;       // continuous head (tanh_normal.h) when not null: (rows, no) actions; log_std follows bhead
-};
 
 __device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
@@ -309,7 +287,7 @@ static int rec_step_impl(const float* actor_params, int actor_din, int n_actions
                          int greedy, int32_t* action, float* action_f, float* log_prob, const float* critic_params,
                          int critic_din, const float* critic_input, int critic_share, const uint8_t* done_c,
                          int done_c_stride, const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
-                         float* value, hipStream_t s) {
+                         float* value, hipStream_t s, const void* pack_a = nullptr, const void* pack_c = nullptr) {
   MAVA_ARG_CHECK(rows_a >= 0 && rows_c >= 0 && rows_a % 32 == 0 && rows_c % 32 == 0, 0,
                  "mava_rec_step_f32: rows must be multiples of 32 (rows_a=%d rows_c=%d)", rows_a, rows_c);
   if (rows_a == 0 && rows_c == 0) return MAVA_OK;
@@ -337,6 +315,10 @@ static int rec_step_impl(const float* actor_params, int actor_din, int n_actions
   so.row_offset = row_offset; so.greedy = greedy; so.action = action; so.log_prob = log_prob; so.value = value;
   so.vbroadcast = value_broadcast;
   so.action_f = action_f;
+  if (pack_a != nullptr && pack_c != nullptr && rows_a > 0 && rows_c > 0) {  // split-f16 operands, pre-packed weights
+    const int rc = mava_rec_step_h2_launch(a, c, pack_a, pack_c, so, s);
+    if (rc <= 0) return rc;
+  }
   const int ta = rows_a / 32, tc = rows_c / 32;
   // one block per CU; the CUs are shared out in proportion to the tiles of the two networks
   int nba = ta, nbc = tc;
@@ -391,4 +373,23 @@ extern "C" int mava_rec_step_continuous_f32(const float* actor_params, int actor
   return rec_step_impl(actor_params, actor_din, action_dim, agents_view, nullptr, done_a, h_actor_in, h_actor_out, rows_a,
                        seed, step, row_offset, greedy, nullptr, action, log_prob, critic_params, critic_din, critic_input,
                        critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s);
+}
+
+// The same acting step on split-f16 operands (rec_step_h2.hip): pack_a / pack_c are the two networks' weights as written
+// by mava_rec_step_pack_f32 from the CURRENT parameters (mava_rec_step_pack_bytes(din) bytes each; re-pack after every
+// parameter update).  Shapes the f16x2 kernel does not instantiate (more than 16 outputs) run the exact-f32 kernel.
+extern "C" int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float* actor_params, int actor_din,
+                                        int n_actions, const float* agents_view, const uint8_t* action_mask,
+                                        const uint8_t* done_a, const float* h_actor_in, float* h_actor_out, int rows_a,
+                                        uint64_t seed, uint32_t step, uint32_t row_offset, int greedy, int32_t* action,
+                                        float* action_f, float* log_prob, const float* critic_params, int critic_din,
+                                        const float* critic_input, int critic_share, const uint8_t* done_c, int done_c_stride,
+                                        const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
+                                        float* value, hipStream_t s) {
+  MAVA_ARG_CHECK(pack_a && pack_c, 5, "mava_rec_step_packed_f32: null weight pack");
+  MAVA_ARG_CHECK(action_f == nullptr || n_actions <= 16, 1, "mava_rec_step_packed_f32: action_dim <= 16 for the continuous head");
+  return rec_step_impl(actor_params, actor_din, n_actions, agents_view, action_f ? nullptr : action_mask, done_a, h_actor_in,
+                       h_actor_out, rows_a, seed, step, row_offset, greedy, action_f ? nullptr : action, action_f, log_prob,
+                       critic_params, critic_din, critic_input, critic_share, done_c, done_c_stride, h_critic_in, h_critic_out,
+                       rows_c, value_broadcast, value, s, pack_a, pack_c);
 }

@@ -146,6 +146,9 @@ class RecLearner:
         self.ws = RecWorkspace(self.T * self.Rm, max(self.nA, 1), d, training=True, din_max=max(self.Oa, self.Oc))
         # the backward chain runs in units of a power of two near the row count (mava_seq_actor_loss_f32: f16 range)
         self.grad_scale = float(2 ** math.ceil(math.log2(self.T * self.Rm)))
+        # f16x2: both networks' weights pre-split in MFMA-fragment order for the fused acting step (re-packed per rollout)
+        self.pack_a = torch.empty(lib().mava_rec_step_pack_bytes(self.Oa), dtype=torch.uint8, device=d)
+        self.pack_c = torch.empty(lib().mava_rec_step_pack_bytes(self.Oc), dtype=torch.uint8, device=d)
         n_slab = max(1, min(NUM_CU, (self.T * self.Rm) // 32))
         self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
@@ -216,6 +219,10 @@ class RecLearner:
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
             rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
         fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0"
+        packed = fused and self.matmul_mode == "f16x2" and self.nA <= 16
+        if packed:  # the parameters are constant during a rollout: split them once (rec_step_h2.hip)
+            check(lib().mava_rec_step_pack_f32(ptr(pa), self.Oa, ptr(self.pack_a), stream_ptr()), "mava_rec_step_pack_f32")
+            check(lib().mava_rec_step_pack_f32(ptr(pc), self.Oc, ptr(self.pack_c), stream_ptr()), "mava_rec_step_pack_f32")
         for t in range(self.T):
             step = self.t_global + t
             for u, rep in enumerate(self.reps):
@@ -230,7 +237,13 @@ class RecLearner:
                                    ptr(d_prev), A if agg else 1, ptr(rep.h_critic), ptr(rep.h_critic_next),
                                    E if agg else EA, A if agg else 1, ptr(rep.value[t]), stream_ptr())
                     rng_args = (self.seed & (2**64 - 1), step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0)
-                    if self.continuous:
+                    if packed:
+                        launch("rec_step", lib().mava_rec_step_packed_f32, ptr(self.pack_a), ptr(self.pack_c),
+                               ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), None if self.continuous else ptr(rep.action_mask[t]),
+                               ptr(d_prev), ptr(rep.h_actor), ptr(rep.h_actor_next), EA, *rng_args,
+                               None if self.continuous else ptr(rep.action[t]), ptr(rep.action[t]) if self.continuous else None,
+                               ptr(rep.log_prob[t]), *critic_args)
+                    elif self.continuous:
                         check(lib().mava_rec_step_continuous_f32(
                             ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(d_prev), ptr(rep.h_actor),
                             ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]), *critic_args),

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import rec_oracle as ro
-from tests.conftest import assert_close
+from tests.conftest import assert_close, check_and_sync_f16x2_state
 
 pytestmark = pytest.mark.gpu
 
@@ -328,23 +328,7 @@ def test_rec_learner_update_matches_oracle(dev, system, U, E, matmul):
             assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
             assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
         else:
-            # f16x2 (~22-bit operands; gradients pinned at 1e-4 of their rms in test_recurrent_gradients_match_autograd):
-            # Adam's g / (sqrt(v) + eps) turns a 1e-4-of-rms difference on an entry near eps (1e-5) into a visible step,
-            # so all but a handful of the parameters are held to 1e-4, every one to 1e-3, and - as in
-            # tests/test_gpu_learner.py - each update is compared from an IDENTICAL state (the learner takes over the
-            # oracle's parameters and Adam moments, rounded to f32, which the oracle then adopts too)
-            Pa = L.Pa
-            for name, got, want in (("actor", L.p[:Pa], ora.pa), ("critic", L.p[Pa:], ora.pc)):
-                got = got.cpu().numpy().astype(np.float64)
-                bad = np.abs(got - want) > 1e-4 * (np.abs(want) + np.sqrt(np.mean(want * want)))
-                assert bad.sum() <= 12, f"{name} params: {int(bad.sum())} entries outside 1e-4"
-                assert_close(got, want, 1e-3, f"{name} params (hard bound)")
-            for dst, a_, c_ in ((L.p, ora.pa, ora.pc), (L.m, ora.ma, ora.mc), (L.v, ora.va, ora.vc)):
-                dst[:Pa].copy_(torch.from_numpy(a_.astype(np.float32)))
-                dst[Pa:].copy_(torch.from_numpy(c_.astype(np.float32)))
-            ora.pa, ora.pc = L.p[:Pa].cpu().numpy().astype(np.float64), L.p[Pa:].cpu().numpy().astype(np.float64)
-            ora.ma, ora.mc = L.m[:Pa].cpu().numpy().astype(np.float64), L.m[Pa:].cpu().numpy().astype(np.float64)
-            ora.va, ora.vc = L.v[:Pa].cpu().numpy().astype(np.float64), L.v[Pa:].cpu().numpy().astype(np.float64)
+            check_and_sync_f16x2_state(L, ora)  # f16x2: see tests/conftest.py
     out = learn(L.learner_state())
     torch.cuda.synchronize()
     assert out.train_metrics["total_loss"].shape == (1, 2, U, K, M) and torch.isfinite(out.train_metrics["total_loss"]).all()

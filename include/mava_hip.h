@@ -330,6 +330,21 @@ int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float
 /* T32 <-> row-major conversion of a (rows x N) matrix. */
 int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);
 
+/* ---- exchange step: replaces the jax.lax.pmean calls of mava/systems/ppo/ff_mappo.py:224-238
+ *      (actor and critic (grads, loss_info) over the "batch" and "device" axes) for a host without torch.distributed.
+ *      One process per GPU: rank 0 obtains a 128-byte id (mava_comm_unique_id) and hands it to the other ranks by any
+ *      host channel; every rank then creates its communicator on ITS current HIP device.  mava_allreduce_sum_f32 sums
+ *      the flat [actor grads | critic grads | loss scalars] buffer over the ranks in place, asynchronously on stream s
+ *      (RCCL over xGMI); the 1 / (update_batch_size * world) of the two pmeans is mava_clip_adam_f32's grad_scale.
+ *      mava_broadcast_f32 replicates rank `root`'s parameters (flax.jax_utils.replicate, ff_mappo.py:426).
+ *      librccl.so is dlopen-ed at the first call (MAVA_RCCL_LIB overrides the name), so a host that already carries an
+ *      RCCL shares it.  RCCL errors come back as -2000 - ncclResult_t. */
+int mava_comm_unique_id(uint8_t* id128);
+int mava_comm_create(void** h, int rank, int world, const uint8_t* id128);
+int mava_allreduce_sum_f32(void* h, float* buf, size_t n, mava_stream_t s);
+int mava_broadcast_f32(void* h, float* buf, size_t n, int root, mava_stream_t s);
+int mava_comm_destroy(void* h);
+
 #ifdef __cplusplus
 }
 #endif

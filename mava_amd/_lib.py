@@ -74,6 +74,11 @@ _SIGNATURES = {
                           i32, i32, vp, vp],
     "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_pack_bytes": [i32],
+    "mava_comm_unique_id": [vp],
+    "mava_comm_create": [vp, i32, i32, vp],
+    "mava_allreduce_sum_f32": [vp, vp, C.c_size_t, vp],
+    "mava_broadcast_f32": [vp, vp, C.c_size_t, i32, vp],
+    "mava_comm_destroy": [vp],
     "mava_rec_step_pack_f32": [vp, i32, vp, vp],
     "mava_rec_step_packed_f32": [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, vp, i32, vp, i32, vp,
                                  i32, vp, vp, i32, i32, vp, vp],

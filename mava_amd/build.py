@@ -32,7 +32,7 @@ HIP_SOURCES = [
     "rec_step.hip",
     "rec_step_h2.hip",
 ]
-CPP_SOURCES = ["api.cpp"]
+CPP_SOURCES = ["api.cpp", "comm.cpp"]
 
 COMMON_FLAGS = ["-O3", "-fPIC", "-std=c++17", "-I", CSRC, "-I", os.path.join(ROOT, "..", "include")]
 HIP_FLAGS = [f"--offload-arch={ARCH}", "-ffp-contract=fast", "-Wno-unused-result"]
@@ -93,7 +93,7 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
         os.path.getmtime(o) > os.path.getmtime(OUT_LIB) for o in objs
     )
     if need_link:
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT_LIB] + objs
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT_LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -46,3 +46,16 @@ def test_product_path_refuses_cpu_tensors():
     r = torch.zeros(4, 8)
     with pytest.raises(_lib.MavaHipError):
         ops.gae(r, r.clone(), torch.zeros(4, 8, dtype=torch.uint8), torch.zeros(8), 0.99, 0.95)
+
+
+def test_comm_abi_argument_errors():
+    """mava_comm_* (csrc/comm.cpp): argument checks run before RCCL is touched."""
+    import ctypes as C
+
+    lib = _lib.lib()
+    assert lib.mava_comm_create(None, 0, 1, None) <= -1000
+    h = C.c_void_p()
+    idb = (C.c_uint8 * 128)()
+    assert lib.mava_comm_create(C.byref(h), 3, 2, idb) <= -1000 and b"rank 3 of 2" in lib.mava_last_error()
+    assert lib.mava_allreduce_sum_f32(None, None, 4, None) <= -1000
+    assert lib.mava_comm_destroy(None) == 0

@@ -123,3 +123,42 @@ def test_two_rank_hip_learner_matches_oracle(dev, system, U, tmp_path):
         assert_close(p[:Pa], ora.pa, 1e-5, "actor params (2 ranks)")
         assert_close(p[Pa:], ora.pc, 1e-5, "critic params (2 ranks)")
         assert_close(got[0][f"metrics{n}"], res["train_metrics"], 1e-4, "train metrics (2 ranks)", scale=1.0)
+
+
+def test_comm_abi_single_rank(dev, monkeypatch):
+    """The C-ABI exchange step on a one-rank RCCL communicator (a box has one GPU): the sum over one rank is the
+    identity, broadcast from root 0 likewise; then a learner update with MAVA_COMM=abi routing its three all-reduces
+    per minibatch through mava_allreduce_sum_f32 gives bit-identical parameters to the plain single-rank update."""
+    import numpy as np
+    import torch
+
+    from mava_amd import envs, parallel
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import ff_mappo
+
+    c = parallel.AbiComm(0, 1)
+    x = torch.arange(1000, dtype=torch.float32, device=dev) * 0.5
+    want = x.clone()
+    c.allreduce_sum_(x)
+    c.broadcast_(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    c.close()
+
+    finals = []
+    for mode in ("abi", ""):
+        monkeypatch.setenv("MAVA_COMM", mode)
+        parallel._abi_comm = None
+        cfg = compose("default_ff_mappo", ["env/scenario=tiny-4ag", "arch.num_envs=16", "system.rollout_length=8",
+                                           "system.ppo_epochs=2", "system.num_minibatches=2", "system.update_batch_size=1"])
+        cfg.env.synthetic = {"obs_dim": 12, "num_actions": 5}
+        env, _ = envs.make(cfg, add_global_state=True, device=dev)
+        learn, _, state = ff_mappo.learner_setup(env, (3, 4, 5), cfg, device=dev)
+        out = learn(state)
+        torch.cuda.synchronize()
+        finals.append(learn.learner.p.clone())
+        if mode == "abi":
+            assert parallel._abi_comm is not None, "the ABI communicator was not used"
+            parallel._abi_comm.close()
+            parallel._abi_comm = None
+    assert torch.equal(finals[0], finals[1])

@@ -216,15 +216,17 @@ int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* c
  * block) gathered per batch row; W (K x N) row-major with row stride ldw; Y T32 (rows x N).  accumulate: start from
  * the existing Y (K-chunked products for inputs wider than 384).  With mava_ppo_set_matmul_mode(1) T32 inputs run on
  * split-f16 operands (rec_dense_h2.hip: 3 f16 MFMAs per product, f32 accumulate, operands must sit in f16 range -
- * see grad_scale below); row-major inputs always run the exact-f32 kernel. */
+ * see grad_scale below); row-major inputs always run the exact-f32 kernel.  y_ld (<= 0: N) is the feature count of the
+ * y / gate tiles: a call with a column block of W and y + 32 * n0 writes features [n0, n0 + N) of a wider matrix. */
 int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                        int x_share, int x_ld, int accumulate, const float* w, int ldw, const float* bias,
-                       const float* gate, float* y, int K, int N, int rows, int relu, mava_stream_t s);
+                       const float* gate, float* y, int y_ld, int K, int N, int rows, int relu, mava_stream_t s);
 
-/* per-block slabs of out_scale * dW = X^T Y (K x N row-major) followed by out_scale * db = colsum(Y) when want_bias.
+/* per-block slabs of out_scale * dW = X^T Y (K x N row-major) followed by out_scale * db = colsum(Y) when want_bias;
+ * y_ld (<= 0: N) = features per y tile (y + 32 * n0 reads a column block of a wider matrix).
  * out_scale undoes the grad_scale the backward chain was started with (1.0f when none). */
 int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                     int x_share, int x_ld, const float* y, int K, int N, int rows, int want_bias, float out_scale,
+                     int x_share, int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
                      float* slab, long slab_stride, int n_slab, mava_stream_t s);
 /* Row-major, env-permuted observation slice of a minibatch (same gather description as mava_rec_dense_f32 with
  * x_rowmajor) -> T32 matrix `out` with k_pad >= K features per tile (zeros past K): done once per minibatch, read by
@@ -261,15 +263,20 @@ int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const in
 /* Continuous head on the recurrent systems (rec_mappo.py:210-242 with networks.py:127-169): `mean` / `dmean` are T32
  * (T*Rm x action_dim) like logits / dlogits of mava_seq_actor_loss_f32, `action` is the external (T, E, A, action_dim)
  * buffer, `log_std` the action_dim raw scales; dscale_partials (n_blocks x action_dim) receives d loss / d log_std
- * partials (already times sigmoid(log_std)).  Entropy noise: Philox counter (row_offset + trajectory row, ent_step, dim/2). */
+ * partials (already times sigmoid(log_std)).  Entropy noise: Philox counter (row_offset + trajectory row, ent_step, dim/2).
+ * ContinuousActionHead(independent_std=False) (networks.py:140,161): log_std_rows is the T32 (T*Rm x action_dim) output
+ * of the log_std layer (log_std may then be NULL) and dlog_std_rows receives its gradient (times grad_scale) instead of
+ * dscale_partials; both NULL for the observation-independent scale. */
 int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
-                                       const float* mean, const float* log_std, const float* action,
-                                       const float* old_log_prob, const float* advantages, const double* adv_stats,
-                                       int n_stats, float clip_eps, float ent_coef, uint64_t seed, uint32_t ent_step,
-                                       uint32_t row_offset, float grad_scale, float* dmean, float* loss_partials,
-                                       float* dscale_partials, int n_blocks, mava_stream_t s);
+                                       const float* mean, const float* log_std, const float* log_std_rows,
+                                       const float* action, const float* old_log_prob, const float* advantages,
+                                       const double* adv_stats, int n_stats, float clip_eps, float ent_coef, uint64_t seed,
+                                       uint32_t ent_step, uint32_t row_offset, float grad_scale, float* dmean,
+                                       float* dlog_std_rows, float* loss_partials, float* dscale_partials, int n_blocks,
+                                       mava_stream_t s);
 /* rollout epilogue: T32 means of one step -> action (rows, action_dim) = tanh(loc + scale * noise), log_prob (rows) */
-int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std, uint64_t seed,
+int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std,
+                                   const float* log_std_rows, uint64_t seed,
                                    uint32_t step, uint32_t row_offset, int greedy, float* action, float* log_prob,
                                    mava_stream_t s);
 /* agents_per_row = 1: one value per agent row (T, E, A).  agents_per_row = n > 1 (then A must be 1): the rows are
@@ -329,6 +336,29 @@ int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float
 
 /* T32 <-> row-major conversion of a (rows x N) matrix. */
 int mava_t32_convert_f32(const float* src, int N, int rows, int to_t32, float* dst, mava_stream_t s);
+
+/* ---- general network path (torsos the fused kernels do not instantiate): mava/networks.py:39-58 MLPTorso with any
+ *      layer_sizes, activation relu | tanh and use_layer_norm, mava/networks.py:61-85 CNNTorso.  Products run on
+ *      mava_rec_dense_f32 / mava_rec_xty_f32; these are the kernels between them.  act: 0 none, 1 relu, 2 tanh. */
+/* y = act(LayerNorm(x) + ln_bias) (flax LayerNorm over the last axis, eps 1e-6, no scale) or act(x); xhat (T32) and
+ * rstd (rows) are saved for the backward pass when use_layer_norm. */
+int mava_t32_norm_act_f32(const float* x, int N, long rows, int use_layer_norm, const float* ln_bias, int act, float* y,
+                          float* xhat, float* rstd, mava_stream_t s);
+/* dz = dy * act'(y) (the bias gradient is its column sum); dx = gradient w.r.t. the layer-norm input (= dz without it) */
+int mava_t32_norm_act_bwd_f32(const float* dy, const float* y, int N, long rows, int use_layer_norm, const float* xhat,
+                              const float* rstd, int act, float* dz, float* dx, mava_stream_t s);
+/* per-block partial column sums of a T32 matrix times `scale`: slab (n_slab, slab_stride >= N) */
+int mava_t32_colsum_f32(const float* y, int N, long rows, float scale, float* slab, long slab_stride, int n_slab,
+                        mava_stream_t s);
+/* nn.Conv(padding='SAME') as a product: patches of (Hin, Win, C) images -> T32 (samples*Hout*Wout x k*k*C), feature
+ * (ky*k + kx)*C + c = a row of the flattened (k, k, C, Cout) kernel.  src_flat = 1: source T32 (samples x Hin*Win*C) (the
+ * gathered observations); 0: source T32 (samples*Hin*Win x C) (the previous conv layer).  col2im is its adjoint. */
+int mava_t32_im2col_f32(const float* src, int src_flat, long samples, int Hin, int Win, int C, int k, int stride,
+                        float* dst, mava_stream_t s);
+int mava_t32_col2im_f32(const float* dcol, int src_flat, long samples, int Hin, int Win, int C, int k, int stride,
+                        float* dsrc, mava_stream_t s);
+/* jax.lax.collapse(x, -3): T32 (samples*P x C) -> T32 (samples x P*C) (to_flat = 1) and back (0) */
+int mava_t32_flatten_f32(const float* src, long samples, int P, int C, int to_flat, float* dst, mava_stream_t s);
 
 /* ---- exchange step: replaces the jax.lax.pmean calls of mava/systems/ppo/ff_mappo.py:224-238
  *      (actor and critic (grads, loss_info) over the "batch" and "device" axes) for a host without torch.distributed.

@@ -51,9 +51,9 @@ _SIGNATURES = {
                                         vp, vp, vp, vp, vp, vp],
     "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32,
                                            u32, vp, lng, i32, vp],
-    "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
-                                           u32, f32, vp, vp, vp, i32, vp],
-    "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
+    "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
+                                           u32, f32, vp, vp, vp, vp, i32, vp],
+    "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_rec_xty_set_variant": [i32],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
@@ -62,8 +62,8 @@ _SIGNATURES = {
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
     "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 14 + [vp, i32, vp],
     "mava_rollout_ff_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, u64, u64, u32, u32, u32, i32] + [vp] * 18 + [vp, vp, f32, f32, vp],
-    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp, lng, i32, vp],
+    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
     "mava_rec_gather_t32_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "mava_gru_scan_bwd_f32": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -74,6 +74,12 @@ _SIGNATURES = {
                           i32, i32, vp, vp],
     "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_pack_bytes": [i32],
+    "mava_t32_norm_act_f32": [vp, i32, lng, i32, vp, i32, vp, vp, vp, vp],
+    "mava_t32_norm_act_bwd_f32": [vp, vp, i32, lng, i32, vp, vp, i32, vp, vp, vp],
+    "mava_t32_colsum_f32": [vp, i32, lng, f32, vp, lng, i32, vp],
+    "mava_t32_im2col_f32": [vp, i32, lng, i32, i32, i32, i32, i32, vp, vp],
+    "mava_t32_col2im_f32": [vp, i32, lng, i32, i32, i32, i32, i32, vp, vp],
+    "mava_t32_flatten_f32": [vp, lng, i32, i32, i32, vp, vp],
     "mava_comm_unique_id": [vp],
     "mava_comm_create": [vp, i32, i32, vp],
     "mava_allreduce_sum_f32": [vp, vp, C.c_size_t, vp],

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
-      const long base = ((long)it * N + fb) * 32 + j;
+      const long base = ((long)it * tk.y_ld + fb) * 32 + j;
       float* const yo = tk.y + base;
       const float* const go = tk.gate != nullptr ? tk.gate + base : nullptr;
 #pragma unroll
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
   // raw gate loads of n-tile 0 for tile `it` (features past N clamp to the tile's first feature)
   auto load_gate = [&](int it, float (&g)[16]) {
     const int fb = 32 * w + 4 * h;
-    const float* const go = tk.gate + ((long)it * N + fb) * 32 + j;
+    const float* const go = tk.gate + ((long)it * tk.y_ld + fb) * 32 + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = go[(fb + (r & 3) + 8 * (r >> 2) < N) ? DOFF(r) : 0];
   };
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_kernel(DenseTask tk) {
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
-      const float* const yo = tk.y + ((long)it * N + fb) * 32 + j;
+      const float* const yo = tk.y + ((long)it * tk.y_ld + fb) * 32 + j;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = fb + (r & 3) + 8 * (r >> 2);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
   float4 xq[KT], yq[NT_ALL];
   const int nx4 = K * 8, ny4 = N * 8;  // float4 per tile
   auto issue = [&](int it) {
-    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * N) * 32);
+    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * tk.y_ld) * 32);
 #pragma unroll
     for (int i = 0; i < NT_ALL; ++i) {
       const int q = tid + 256 * i;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_bf16x6_kernel(XtyTask tk) {
   for (int i = 0; i < NT_ALL; ++i) bacc[i] = 0.0f;
   const int nx4 = K * 8, ny4 = N * 8;  // float4 per tile
   auto issue = [&](int it) {
-    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * N) * 32);
+    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * tk.y_ld) * 32);
 #pragma unroll
     for (int i = 0; i < NT_ALL; ++i) {
       const int q = tid + 256 * i;
@@ -632,7 +632,7 @@ int launch_dense(const DenseTask& tk, hipStream_t s) {
     return MAVA_EARG(9);
   }
   if (tk.K == 16 * NB) return launch_dense_rm<NB, NTW, false, true>(tk, s);
-  if (NB <= 2 && NTW == 1) return launch_dense_rm<(NB <= 2 ? NB : 2), 1, false, false>(tk, s);  // n_out-wide inputs
+  if (NTW == 1) return launch_dense_rm<NB, 1, false, false>(tk, s);  // any width: clamped operand addresses
   mava_set_error("mava_rec_dense_f32: T32 input width K=%d is not instantiated for N=%d (T32 inputs: K <= 32, or K in "
                  "{64,96,128,192,288,384} with N <= 128, or K = 128 / 192 with N <= 384 / 256)", tk.K, tk.N);
   return MAVA_EARG(9);
@@ -684,8 +684,9 @@ extern "C" int mava_rec_xty_set_variant(int v) {
 
 extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                                   int x_share, int x_ld, int accumulate, const float* w, int ldw,
-                                  const float* bias, const float* gate, float* y, int K, int N, int rows,
+                                  const float* bias, const float* gate, float* y, int y_ld, int K, int N, int rows,
                                   int relu, hipStream_t s) {
+  if (y_ld <= 0) y_ld = N;
   if (!x_rowmajor && x_ld <= 0) x_ld = K;
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384 && ldw >= N, 0,
                  "mava_rec_dense_f32: K=%d N=%d ldw=%d unsupported (K, N <= 384)", K, N, ldw);
@@ -695,13 +696,12 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
   MAVA_ARG_CHECK(!x_rowmajor || (Rm >= 1 && A >= 1 && E >= 1 && x_share >= 1 && rows % Rm == 0 && x_ld >= K), 3,
                  "mava_rec_dense_f32: bad gather description Rm=%d E=%d A=%d x_ld=%d", Rm, E, A, x_ld);
   MAVA_ARG_CHECK(x_rowmajor || x_ld >= K, 5, "mava_rec_dense_f32: T32 input with %d features per tile < K=%d", x_ld, K);
-  DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, accumulate, w, ldw, bias, gate, y, K, N, rows, relu};
+  MAVA_ARG_CHECK(y_ld >= N, 7, "mava_rec_dense_f32: y_ld=%d < N=%d", y_ld, N);
+  DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, accumulate, w, ldw, bias, gate, y, K, N, rows, relu, y_ld};
   if (mava_ppo_get_matmul_mode() == 1) {
     const int rc = mava_rec_dense_h2_launch(tk, s);
     if (rc <= 0) return rc;
   }
-  MAVA_ARG_CHECK(x_rowmajor || x_ld == K || K % 16 == 0, 6,
-                 "mava_rec_dense_f32: a padded T32 input (K=%d of %d features) needs K %% 16 == 0 in the f32 kernel", K, x_ld);
   const int nb = (K + 15) / 16;
   const int ntw = ((N + 31) / 32 + 3) / 4;  // n-tiles per wave
   MAVA_ARG_CHECK(nb * ntw * 8 <= 192, 4, "mava_rec_dense_f32: weight slice of %d registers does not fit (K=%d N=%d)",
@@ -716,16 +716,18 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
 }
 
 extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
-                                int x_ld, const float* y, int K, int N, int rows, int want_bias, float out_scale,
+                                int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
                                 float* slab, long slab_stride, int n_slab, hipStream_t s) {
   if (!x_rowmajor && x_ld <= 0) x_ld = K;
+  if (y_ld <= 0) y_ld = N;
+  MAVA_ARG_CHECK(y_ld >= N, 6, "mava_rec_xty_f32: y_ld=%d < N=%d", y_ld, N);
   MAVA_ARG_CHECK(K >= 1 && K <= 384 && N >= 1 && N <= 384, 0, "mava_rec_xty_f32: K=%d N=%d unsupported", K, N);
   MAVA_ARG_CHECK(rows >= 32 && rows % 32 == 0 && n_slab >= 1 && n_slab <= 1024, 1,
                  "mava_rec_xty_f32: rows=%d n_slab=%d", rows, n_slab);
   MAVA_ARG_CHECK(slab_stride >= (long)K * N + (want_bias ? N : 0), 2, "mava_rec_xty_f32: slab_stride too small");
   MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
   MAVA_ARG_CHECK(x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
-  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, slab, slab_stride, want_bias, out_scale};
+  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, y_ld, slab, slab_stride, want_bias, out_scale};
   if (mava_ppo_get_matmul_mode() == 1 && g_xty_variant == 0) {
     const int rc = mava_rec_xty_h2_launch(tk, n_slab, s);
     if (rc <= 0) return rc;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
       const int fb = 32 * (w + 4 * tw) + 4 * h;
-      const long base = ((long)it * N + fb) * 32 + j;
+      const long base = ((long)it * tk.y_ld + fb) * 32 + j;
       float* const yo = tk.y + base;
       const float* const go = tk.gate != nullptr ? tk.gate + base : nullptr;
       if (32 * (w + 4 * tw) + 32 <= N) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
   };
   auto load_gate = [&](int it, float (&g)[16]) {
     const int fb = 32 * w + 4 * h;
-    const float* const go = tk.gate + ((long)it * N + fb) * 32 + j;
+    const float* const go = tk.gate + ((long)it * tk.y_ld + fb) * 32 + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = go[(fb + (r & 3) + 8 * (r >> 2) < N) ? DOFF(r) : 0];
   };
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
         const int fb = 32 * (w + 4 * tw) + 4 * h;
-        const float* const yo = tk.y + ((long)it * N + fb) * 32 + j;
+        const float* const yo = tk.y + ((long)it * tk.y_ld + fb) * 32 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (fb + (r & 3) + 8 * (r >> 2) < N) acc[tw][r] += yo[DOFF(r)];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
       const int q = tid + 256 * k;
       raw[k] = xs[q < nx4 ? q : (nx4 - 1)];
     } else {
-      const float4* ys = reinterpret_cast<const float4*>(tk.y + (long)it * N * 32);
+      const float4* ys = reinterpret_cast<const float4*>(tk.y + (long)it * tk.y_ld * 32);
       const int q = tid + 256 * (k - KT);
       raw[k] = ys[q < ny4 ? q : (ny4 - 1)];
     }

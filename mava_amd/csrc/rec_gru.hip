@@ -262,6 +262,8 @@ struct SeqLossTask {
   float* value_out;
   // continuous head (tanh_normal.h): y holds the means
   const float* log_std;      // (no) raw scales
+  const float* log_std_rows; // T32 (rows x no) raw scales per row (ContinuousActionHead(independent_std=False)) or null
+  float* dlog_std_rows;      // T32: d loss / d raw scale per row (times grad_scale), with log_std_rows
   const float* action_f;     // external (T, E, A, no) actions in (-1, 1)
   float* action_f_out;       // external (E, A, no) slot
   float* dscale_partials;    // (gridDim.x, no): d loss / d log_std partials
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
   float sc[NO], ds[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
-    sc[o] = tn::scale_of(tk.log_std[o < tk.no ? o : 0]);
+    sc[o] = tk.log_std != nullptr ? tn::scale_of(tk.log_std[o < tk.no ? o : 0]) : 1.0f;
     ds[o] = 0.0f;
   }
   float la = 0.0f, lb = 0.0f;
@@ -437,13 +439,17 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
     const long er = ((long)t * tk.E + env) * tk.A + a;
     const long tile = q >> 5;
     const int jj = (int)(q & 31);
-    float dm[NO], dsl[NO], th[NO], ep[NO];
+    float dm[NO], dsl[NO], th[NO], ep[NO], lsr[NO];
     float lp = 0.0f, ent = 0.0f;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-      dm[o] = dsl[o] = th[o] = ep[o] = 0.0f;
+      dm[o] = dsl[o] = th[o] = ep[o] = lsr[o] = 0.0f;
       if (o < tk.no) {
         const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
+        if (tk.log_std_rows != nullptr) {  // state-dependent scale: networks.py:140,161
+          lsr[o] = tk.log_std_rows[(tile * tk.no + o) * 32 + jj];
+          sc[o] = tn::scale_of(lsr[o]);
+        }
         const tn::LogProb l = tn::log_prob(tk.action_f[er * tk.no + o], mean, sc[o]);
         lp += l.lp;
         dm[o] = l.dmean;
@@ -467,7 +473,9 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
     for (int o = 0; o < NO; ++o) {
       if (o < tk.no) {
         tk.dy[(tile * tk.no + o) * 32 + jj] = (dlp * dm[o] + ec * 2.0f * th[o]) * tk.grad_scale;
-        ds[o] += dlp * dsl[o] - ec * (1.0f / sc[o] - 2.0f * th[o] * ep[o]);
+        const float dsc = dlp * dsl[o] - ec * (1.0f / sc[o] - 2.0f * th[o] * ep[o]);
+        if (tk.dlog_std_rows != nullptr) tk.dlog_std_rows[(tile * tk.no + o) * 32 + jj] = dsc * tn::sigmoid(lsr[o]) * tk.grad_scale;
+        else ds[o] += dsc;
       }
     }
     la += -fminf(l1, l2) * invR;
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
   __syncthreads();
   if (threadIdx.x < 2) tk.loss_partials[2 * blockIdx.x + threadIdx.x] =
       ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
-  if ((int)threadIdx.x < tk.no) {
+  if ((int)threadIdx.x < tk.no && tk.log_std != nullptr) {
     const int k = threadIdx.x;  // d scale / d log_std = sigmoid(log_std)
     tk.dscale_partials[(long)blockIdx.x * tk.no + k] =
         (((red[2 + k][0] + red[2 + k][1]) + red[2 + k][2]) + red[2 + k][3]) * tn::sigmoid(tk.log_std[k]);
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) void seq_sample_cont_kernel(SeqLossTask tk) {
   for (int o = 0; o < NO; ++o) {
     if (o < tk.no) {
       const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
-      const float sc = tn::scale_of(tk.log_std[o]);
+      const float sc = tn::scale_of(tk.log_std_rows != nullptr ? tk.log_std_rows[(tile * tk.no + o) * 32 + jj] : tk.log_std[o]);
       const float eps = tk.greedy ? 0.0f : tn::noise(gid, tk.step, o, tn::STREAM_SAMPLE, tk.seed_lo, tk.seed_hi);
       const float a = tanhf(fmaf(sc, eps, mean));
       lp += tn::log_prob(a, mean, sc).lp;
@@ -596,20 +604,23 @@ extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_action
 }
 
 extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
-                                                  const float* mean, const float* log_std, const float* action,
+                                                  const float* mean, const float* log_std, const float* log_std_rows,
+                                                  const float* action,
                                                   const float* old_log_prob, const float* advantages,
                                                   const double* adv_stats, int n_stats, float clip_eps, float ent_coef,
                                                   uint64_t seed, uint32_t ent_step, uint32_t row_offset,
-                                                  float grad_scale, float* dmean,
+                                                  float grad_scale, float* dmean, float* dlog_std_rows,
                                                   float* loss_partials, float* dscale_partials, int n_blocks,
                                                   hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm % 32 == 0 && action_dim >= 1 && action_dim <= 16 && n_blocks >= 1, 0,
                  "mava_seq_actor_loss_continuous_f32: bad shape (action_dim <= 16)");
-  MAVA_ARG_CHECK(mean && log_std && action && old_log_prob && advantages && adv_stats && dmean && loss_partials &&
-                 dscale_partials, 1, "mava_seq_actor_loss_continuous_f32: null pointer argument");
+  MAVA_ARG_CHECK(mean && (log_std || log_std_rows) && action && old_log_prob && advantages && adv_stats && dmean && loss_partials &&
+                 (dscale_partials || log_std_rows), 1, "mava_seq_actor_loss_continuous_f32: null pointer argument");
   SeqLossTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.no = action_dim; tk.idx = idx; tk.y = mean; tk.dy = dmean;
-  tk.log_std = log_std; tk.action_f = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
+  MAVA_ARG_CHECK((log_std_rows == nullptr) == (dlog_std_rows == nullptr), 2,
+                 "mava_seq_actor_loss_continuous_f32: log_std_rows and dlog_std_rows come together");
+  tk.log_std = log_std; tk.log_std_rows = log_std_rows; tk.dlog_std_rows = dlog_std_rows; tk.action_f = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
   tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = ent_coef; tk.loss_partials = loss_partials;
   tk.dscale_partials = dscale_partials; tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32);
   tk.ent_step = ent_step; tk.row_offset = row_offset; tk.grad_scale = grad_scale;
@@ -620,13 +631,13 @@ extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, i
 }
 
 extern "C" int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std,
-                                              uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
+                                              const float* log_std_rows, uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
                                               float* action, float* log_prob, hipStream_t s) {
   MAVA_ARG_CHECK(rows >= 1 && rows % 32 == 0 && action_dim >= 1 && action_dim <= 16, 0,
                  "mava_seq_sample_continuous_f32: rows=%d action_dim=%d", rows, action_dim);
-  MAVA_ARG_CHECK(mean && log_std && action && log_prob, 1, "mava_seq_sample_continuous_f32: null pointer argument");
+  MAVA_ARG_CHECK(mean && (log_std || log_std_rows) && action && log_prob, 1, "mava_seq_sample_continuous_f32: null pointer argument");
   SeqLossTask tk = {};
-  tk.Rm = rows; tk.no = action_dim; tk.y = mean; tk.log_std = log_std; tk.seed_lo = (uint32_t)seed;
+  tk.Rm = rows; tk.no = action_dim; tk.y = mean; tk.log_std = log_std; tk.log_std_rows = log_std_rows; tk.seed_lo = (uint32_t)seed;
   tk.seed_hi = (uint32_t)(seed >> 32); tk.step = step; tk.row_offset = row_offset; tk.greedy = greedy;
   tk.action_f_out = action; tk.logp_out = log_prob;
   const int blocks = mava_cdiv(rows, 256);

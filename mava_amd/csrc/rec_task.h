@@ -20,6 +20,7 @@ struct DenseTask {
   const float* gate;     // T32 (rows x N) or null: output multiplied by (gate > 0)
   float* y;              // T32 (rows x N)
   int K, N, rows, relu;
+  int y_ld;              // features per y / gate tile (>= N: a call can write a column block of a wider matrix)
 };
 
 __device__ __forceinline__ long gather_row(const DenseTask& tk, int q) {
@@ -37,6 +38,7 @@ struct XtyTask {
   int x_ld;
   const float* y;      // T32 (rows x N)
   int K, N, rows;
+  int y_ld;            // features per y tile (>= N: a call can read a column block of a wider matrix)
   float* slab;         // (gridDim.x, slab_stride): [dW (K x N row-major) | db (N)]
   long slab_stride;
   int want_bias;

@@ -268,7 +268,7 @@ class RecLearner:
                                                     A, training=False)
                 rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
                 if self.continuous:
-                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, ptr(ws.y), ptr(self.actor_network.log_std(pa)),
+                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, ptr(ws.y), ptr(self.actor_network.log_std(pa)), None,
                                                                self.seed & (2**64 - 1), step & 0xFFFFFFFF,
                                                                ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]),
                                                                ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_continuous_f32")
@@ -338,10 +338,10 @@ class RecLearner:
             ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
             if self.continuous:
                 check(L.mava_seq_actor_loss_continuous_f32(
-                    T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), ptr(rep.action),
+                    T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
                     ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
                     self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
-                    self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
+                    self.grad_scale, ptr(ws.dy), None, ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
                 ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
             else:
                 check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),

@@ -181,21 +181,21 @@ class _RecurrentNet:
             last = k0 + kc >= din
             if t32_in:  # column block k0 of a T32 tile starts k0 * 32 floats into the tile
                 launch("rec_dense(pre)", L.mava_rec_dense_f32, ws.xin.data_ptr() + 4 * 32 * k0, 0, None, 0, 0, 0, 1, kp, int(k0 > 0),
-                       Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows, int(last), s)
+                       Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), 0, kc, H, rows, int(last), s)
             else:
                 launch("rec_dense(pre)", L.mava_rec_dense_f32, x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din,
-                       int(k0 > 0), Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), kc, H, rows,
+                       int(k0 > 0), Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), 0, kc, H, rows,
                        int(last), s)
             k0 += kc
-        launch("rec_dense(gi)", L.mava_rec_dense_f32, ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), H,
+        launch("rec_dense(gi)", L.mava_rec_dense_f32, ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), 0, H,
                G3, rows, 0, s)
         launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
                ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
         launch("rec_dense(post)", L.mava_rec_dense_f32, ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None,
-               ptr(ws.post), H, H, rows, 1, s)
+               ptr(ws.post), 0, H, H, rows, 1, s)
         y = ws.y if y_out is None else y_out
         launch("rec_dense(head)", L.mava_rec_dense_f32, ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"),
-               None, ptr(y), H, self.n_out, rows, 0, s)
+               None, ptr(y), 0, H, self.n_out, rows, 0, s)
         return y
 
     def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
@@ -211,7 +211,7 @@ class _RecurrentNet:
         WpostT = self.seg(flat, "Wpost").t().contiguous()
         WiT = self.seg(flat, "Wi").t().contiguous()
         d = lambda k, N, x, w, ldw, gate, y: launch(
-            "rec_dense(bwd)", L.mava_rec_dense_f32, ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), k, N,
+            "rec_dense(bwd)", L.mava_rec_dense_f32, ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), 0, k, N,
             rows, 0, s)
         d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
         d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
@@ -221,7 +221,7 @@ class _RecurrentNet:
 
         def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
             """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
-            launch("rec_xty", L.mava_rec_xty_f32, x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), K, N,
+            launch("rec_xty", L.mava_rec_xty_f32, x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0, K, N,
                    rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
             ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
             if b_off is not None:

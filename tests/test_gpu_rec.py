@@ -50,7 +50,7 @@ def test_rec_dense_t32(dev, K, N, relu, gated, rec_mode):
     g = rng.standard_normal((rows, N)).astype(np.float32)
     y = torch.zeros(rows * N, device=dev)
     xt, wt, bt, gt = _t(_to_t32(x), dev), _t(w, dev), _t(b, dev), _t(_to_t32(g), dev)
-    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), K, N,
+    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), 0, K, N,
                                    rows, int(relu), stream_ptr()), "dense")
     torch.cuda.synchronize()
     want = x.astype(np.float64) @ w.astype(np.float64) + b
@@ -79,7 +79,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     # freed - and its block recycled by the caching allocator - before the asynchronous kernel reads it)
     obs_d, idx_d, w_d, b_d = _t(obs, dev), _t(idx, dev), _t(w, dev), _t(b, dev)
     check(lib().mava_rec_dense_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, 0, ptr(w_d), N, ptr(b_d), None,
-                                   ptr(y), K, N, rows, 1, stream_ptr()), "dense gather")
+                                   ptr(y), 0, K, N, rows, 1, stream_ptr()), "dense gather")
     xg = obs[:, idx].reshape(rows, K).astype(np.float64)  # time-major, env-major inside a step
     want = np.maximum(xg @ w.astype(np.float64) + b, 0)
     got = _from_t32(y.cpu().numpy(), rows, N)
@@ -88,14 +88,14 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     gs = rng.standard_normal((T, E, K)).astype(np.float32)
     gs_d = _t(gs, dev)
     check(lib().mava_rec_dense_f32(ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, K, 0, ptr(w_d), N, ptr(b_d), None,
-                                   ptr(y), K, N, rows, 0, stream_ptr()), "dense gather shared")
+                                   ptr(y), 0, K, N, rows, 0, stream_ptr()), "dense gather shared")
     want2 = np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64) @ w.astype(np.float64) + b
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want2, 1e-5, "dense gather shared")
     # X^T Y with both input kinds
     dy = rng.standard_normal((rows, N)).astype(np.float32)
     dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), K, N, rows, 1, 1.0,
+    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), 0, K, N, rows, 1, 1.0,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -106,7 +106,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
     x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 128, 384, rows, 1, 0.25,
+    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 0, 128, 384, rows, 1, 0.25,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
@@ -122,12 +122,12 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
         got_x = _from_t32(xin.cpu().numpy(), rows, kp)
         assert np.array_equal(got_x[:, :K], xs.astype(np.float32)) and not got_x[:, K:].any(), "gathered T32 input"
         if rec_mode == 1:  # (the exact-f32 kernel reads padded T32 inputs only when K is a multiple of 16)
-            check(lib().mava_rec_dense_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, 0, ptr(w_d), N, ptr(b_d), None, ptr(y), K, N, rows, 1,
+            check(lib().mava_rec_dense_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, 0, ptr(w_d), N, ptr(b_d), None, ptr(y), 0, K, N, rows, 1,
                                            stream_ptr()), "dense on the gathered input")
             assert_close(_from_t32(y.cpu().numpy(), rows, N), np.maximum(xs @ w.astype(np.float64) + b, 0), 1e-5,
                          "dense, gathered T32")
         slab = torch.zeros((5, K * N + N), device=dev)
-        check(lib().mava_rec_xty_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
+        check(lib().mava_rec_xty_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
                                      stream_ptr()), "xty on the gathered input")
         out = torch.zeros(K * N + N, device=dev)
         ops.slab_reduce(slab, K * N + N, out)
@@ -343,7 +343,7 @@ def test_rec_dense_rejects_unsupported_t32_width(dev):
     w = torch.zeros(155 * 128, device=dev)
     y = torch.zeros(32 * 128, device=dev)
     with pytest.raises(MavaHipError):
-        check(lib().mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, 155, 0, ptr(w), 128, None, None, ptr(y), 155, 128, 32, 0,
+        check(lib().mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, 155, 0, ptr(w), 128, None, None, ptr(y), 0, 155, 128, 32, 0,
                                        stream_ptr()), "dense")
 
 

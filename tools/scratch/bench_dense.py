@@ -20,14 +20,14 @@ for (K, N, relu, gated, name) in ((128, 384, 0, 0, "gi"), (128, 128, 1, 0, "post
     x = torch.randn(rows * K, device=dev); w = torch.randn(K * N, device=dev) * 0.1; b = torch.randn(N, device=dev)
     g = torch.randn(rows * N, device=dev) if gated else None
     y = torch.empty(rows * N, device=dev)
-    us = t(lambda: check(L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, K, 0, ptr(w), N, ptr(b), ptr(g), ptr(y), K, N, rows, relu, stream_ptr()), "d"))
+    us = t(lambda: check(L.mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, K, 0, ptr(w), N, ptr(b), ptr(g), ptr(y), 0, K, N, rows, relu, stream_ptr()), "d"))
     by = rows * 4 * (K + N + (N if gated else 0))
     print(f"dense {name:6s} K={K:3d} N={N:3d}: {us:7.1f} us  {by / us / 1e6:6.2f} TB/s")
     del x, y, g
 slab = torch.zeros((256, 128 * 384 + 384 + 8), device=dev)
 for (K, N, name) in ((128, 384, "Wi/Wh"), (128, 128, "Wpost"), (128, 13, "Whead"), (160, 128, "Wpre")):
     x = torch.randn(rows * K, device=dev); y = torch.randn(rows * N, device=dev)
-    us = t(lambda: check(L.mava_rec_xty_f32(ptr(x), 0, None, 0, 0, 0, 1, K, ptr(y), K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 256, stream_ptr()), "x"))
+    us = t(lambda: check(L.mava_rec_xty_f32(ptr(x), 0, None, 0, 0, 0, 1, K, ptr(y), 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 256, stream_ptr()), "x"))
     by = rows * 4 * (K + N)
     print(f"xty   {name:6s} K={K:3d} N={N:3d}: {us:7.1f} us  {by / us / 1e6:6.2f} TB/s")
     del x, y

@@ -18,7 +18,7 @@ for K in (5, 13, 16, 20, 32):
     b = rng.standard_normal(N).astype(np.float32)
     y = torch.zeros(rows * N, device=dev)
     xt, wt, bt = torch.from_numpy(to_t32(x)).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
-    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), None, ptr(y), K, N, rows, 0, stream_ptr()), "dense")
+    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), None, ptr(y), 0, K, N, rows, 0, stream_ptr()), "dense")
     torch.cuda.synchronize()
     want = x.astype(np.float64) @ w.astype(np.float64) + b
     got = from_t32(y.cpu().numpy(), rows, N)

@@ -61,12 +61,18 @@ class SyntheticRware:
             raise ValueError(f"reward_mode must be 'random' or 'match', got {reward_mode!r}")
         self.reward_mode = reward_mode
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # image view of the observation / state vectors for CNN torsos: (H, W, C) with H*W*C = obs_dim / state_dim
+        # (env.synthetic.obs_shape / state_shape; Mava's CNN environments emit such observations natively)
+        self.obs_shape: Optional[tuple] = None
+        self.state_shape: Optional[tuple] = None
 
     def clone(self, env_offset: int, num_envs: Optional[int] = None) -> "SyntheticRware":
         """Same environment family on a disjoint range of global env ids (one per replica / rank)."""
-        return SyntheticRware(num_envs or self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.time_limit,
-                              self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device,
-                              self.synth_state_dim, self.reward_mode)
+        c = SyntheticRware(num_envs or self.num_envs, self.num_agents, self.raw_obs_dim, self.action_dim, self.time_limit,
+                           self.add_global_state, True, self.seed, env_offset, self.gs_tiles != 1, self.device,
+                           self.synth_state_dim, self.reward_mode)
+        c.obs_shape, c.state_shape = self.obs_shape, self.state_shape
+        return c
 
     # ---- specs ----------------------------------------------------------------------------
     @property
@@ -173,4 +179,7 @@ def make(config, add_global_state: bool = False, device=None, env_offset: int = 
     # The evaluation envs draw from their own Philox KEY (not an env-id offset: the kernel forms the per-agent counter
     # (env_offset + e) * A + agent in 32 bits, where an offset of 2^30 wraps back onto the training envs for A >= 4).
     evale = SyntheticRware(num_envs=int(config.arch.num_eval_episodes), env_offset=env_offset, seed=seed ^ EVAL_KEY_TAG, **kw)
+    for e in (train, evale):
+        e.obs_shape = tuple(int(v) for v in syn["obs_shape"]) if syn.get("obs_shape", None) else None
+        e.state_shape = tuple(int(v) for v in syn["state_shape"]) if syn.get("state_shape", None) else None
     return train, evale

@@ -337,3 +337,128 @@ class GenericWorkspace:
             min_tiles = rows // 32  # every X^T Y block must own a tile of the smallest product
             self.slabs = torch.zeros((max(1, min(n_slab, min_tiles)), 128 * 128 + 128 + 8), device=device)
             self.loss_partials = torch.zeros((1024, 2), device=device)
+
+
+class _GenericFF:
+    """Shared part of the general feed-forward actor / critic: Flax-shaped trees over GenericNet's flat layout."""
+
+    net: GenericNet
+
+    @property
+    def num_params(self) -> int:
+        return self.net.num_params
+
+    def first_leaf(self, tree: Dict[str, Any]) -> torch.Tensor:
+        return tree["params"]["torso"][self.net.layers[0].name]["kernel"]
+
+    def _apply_rows(self, flat: torch.Tensor, x: torch.Tensor) -> List[torch.Tensor]:
+        """Head outputs [(rows, n_out)] for row-major x (rows, din); rows are padded to the 32-row tiles.  Off the timed
+        path (evaluator, tests)."""
+        from .rec_networks import t32_to_rows
+
+        R = int(x.shape[0])
+        Rp = -(-R // 32) * 32
+        xp = torch.zeros((1, Rp, 1, self.net.din), device=x.device)
+        xp[0, :R, 0] = x.float()
+        ws = self.net.workspace(Rp, x.device, training=False)
+        outs = self.net.forward(flat.contiguous().float(), ws, xp, 1, None, Rp, Rp, 1)
+        return [t32_to_rows(o, hd.N, Rp)[:R] for o, hd in zip(outs, self.net.heads)]
+
+
+class GenericActor(_GenericFF):
+    """mava/networks.py:172-183 (FeedForwardActor) over any torso and action head."""
+
+    def __init__(self, torso, action_head, obs_dim: int, obs_shape=None):
+        from .networks import ContinuousActionHead
+
+        self.action_head = action_head
+        self.continuous = isinstance(action_head, ContinuousActionHead)
+        self.independent_std = bool(getattr(action_head, "independent_std", True))
+        self.n_out = int(action_head.action_dim)
+        heads = [("mean" if self.continuous else "Dense_0", self.n_out, 0.01)]
+        if self.continuous and not self.independent_std:
+            heads.append(("log_std", self.n_out, 0.01))
+        self.net = GenericNet(torso, obs_dim, heads, obs_shape, raw_tail=self.n_out if (self.continuous and self.independent_std) else 0)
+        self.din = int(obs_dim)
+
+    def init_flat(self, seed: int, device=None) -> torch.Tensor:
+        return self.net.init_flat(seed, device)  # (the raw log_std tail stays zero: networks.py:141)
+
+    def log_std(self, flat: torch.Tensor) -> torch.Tensor:
+        return flat[self.net.num_net_params : self.net.num_net_params + self.n_out]
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        head: Dict[str, Any] = {self.net.heads[0].name: self.net.head_leaf(flat, 0, lead)}
+        if self.continuous:
+            if self.independent_std:
+                ls = self.log_std(flat)
+                head["log_std"] = ls.expand(*lead, self.n_out) if lead else ls
+            else:
+                head["log_std"] = self.net.head_leaf(flat, 1, lead)
+        return {"params": {"torso": self.net.torso_tree(flat, lead), "action_head": head}}
+
+    def flat_from_tree(self, tree: Dict[str, Any], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        p = tree["params"]
+        if out is None:
+            out = torch.empty(self.num_params, dtype=torch.float32, device=self.first_leaf(tree).device)
+        self.net.load_torso_tree(p["torso"], out)
+        self.net.load_head_leaf(p["action_head"][self.net.heads[0].name], 0, out)
+        if self.continuous:
+            if self.independent_std:
+                ls = torch.as_tensor(p["action_head"]["log_std"])
+                while ls.dim() > 1:
+                    ls = ls[0]
+                self.log_std(out).copy_(ls)
+            else:
+                self.net.load_head_leaf(p["action_head"]["log_std"], 1, out)
+        return out
+
+    def apply(self, params: Any, observation):
+        """actor_network.apply(params, observation) -> distribution (mava/evaluator.py:182-183)."""
+        from .distributions import Categorical, TanhNormal
+
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        av = observation.agents_view
+        lead = av.shape[: av.dim() - (3 if (self.net.is_cnn and av.shape[-1] != self.din) else 1)]
+        outs = self._apply_rows(flat, av.reshape(-1, self.din))
+        if self.continuous:
+            ls = self.log_std(flat.float()) if self.independent_std else outs[1].view(*lead, self.n_out)
+            return TanhNormal(outs[0].view(*lead, self.n_out), ls)
+        mask = observation.action_mask
+        return Categorical(outs[0].view(*lead, self.n_out), None if mask is None else mask.reshape(*lead, self.n_out))
+
+
+class GenericCritic(_GenericFF):
+    """mava/networks.py:186-207 (FeedForwardValueNet) over any torso."""
+
+    def __init__(self, torso, centralised_critic: bool, input_dim: int, obs_shape=None):
+        self.centralised_critic = centralised_critic
+        self.net = GenericNet(torso, input_dim, [("Dense_0", 1, 1.0)], obs_shape)
+        self.din = int(input_dim)
+
+    def init_flat(self, seed: int, device=None) -> torch.Tensor:
+        return self.net.init_flat(seed, device)
+
+    def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
+        return {"params": {"torso": self.net.torso_tree(flat, lead), "Dense_0": self.net.head_leaf(flat, 0, lead)}}
+
+    def flat_from_tree(self, tree: Dict[str, Any], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        p = tree["params"]
+        if out is None:
+            out = torch.empty(self.num_params, dtype=torch.float32, device=self.first_leaf(tree).device)
+        self.net.load_torso_tree(p["torso"], out)
+        self.net.load_head_leaf(p["Dense_0"], 0, out)
+        return out
+
+    def apply(self, params: Any, observation) -> torch.Tensor:
+        from .types import ObservationGlobalState
+
+        if self.centralised_critic:
+            if not isinstance(observation, ObservationGlobalState):
+                raise ValueError("Global state must be provided to the centralised critic.")  # mava/networks.py:196-197
+            x = observation.global_state
+        else:
+            x = observation.agents_view
+        flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
+        lead = x.shape[: x.dim() - (3 if (self.net.is_cnn and x.shape[-1] != self.din) else 1)]
+        return self._apply_rows(flat, x.reshape(-1, self.din))[0].view(*lead)

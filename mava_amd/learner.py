@@ -117,10 +117,27 @@ class FFLearner:
 
         # networks (ff_mappo.py:347-354) - hydra.utils.instantiate is replaced by direct construction
         net = config.network
-        a_torso = MLPTorso(**{k: v for k, v in net.actor_network.pre_torso.items() if k != "_target_"})
-        c_torso = MLPTorso(**{k: v for k, v in net.critic_network.pre_torso.items() if k != "_target_"})
-        self.actor_network = FeedForwardActor(a_torso, action_head, self.Oa)
-        self.critic_network = FeedForwardValueNet(c_torso, centralised_critic, self.Oc)
+        # The default configuration (network/mlp.yaml: [128, 128] relu torsos, observation-independent log_std) runs on the
+        # fused kernels; any other torso (layer sizes, tanh, layer norm, CNNTorso) or ContinuousActionHead(
+        # independent_std=False) runs on the general layer-wise path (mava_amd/generic_networks.py).
+        from . import generic_networks as gn
+
+        self.generic = (not gn.is_default_mlp(net.actor_network.pre_torso) or not gn.is_default_mlp(net.critic_network.pre_torso)
+                        or (self.continuous and not action_head.independent_std))
+        if self.generic:
+            if (self.E * env0.num_agents) % 32 or ((self.T * self.E // self.M) * env0.num_agents) % 32:
+                raise ValueError("the general network path needs num_envs * num_agents and the agent rows of a minibatch to be "
+                                 "multiples of 32")
+            obs_shape = getattr(env0, "obs_shape", None)
+            state_shape = getattr(env0, "state_shape", None) if centralised_critic else obs_shape
+            self.actor_network = gn.GenericActor(gn.torso_from_config(net.actor_network.pre_torso), action_head, self.Oa, obs_shape)
+            self.critic_network = gn.GenericCritic(gn.torso_from_config(net.critic_network.pre_torso), centralised_critic, self.Oc,
+                                                   state_shape)
+        else:
+            a_torso = MLPTorso(**{k: v for k, v in net.actor_network.pre_torso.items() if k != "_target_"})
+            c_torso = MLPTorso(**{k: v for k, v in net.critic_network.pre_torso.items() if k != "_target_"})
+            self.actor_network = FeedForwardActor(a_torso, action_head, self.Oa)
+            self.critic_network = FeedForwardValueNet(c_torso, centralised_critic, self.Oc)
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
         self.P = self.Pa + self.Pc
 
@@ -150,7 +167,7 @@ class FFLearner:
         # 22.5 vs 22.1 ms per update; two gloo ranks on one card: 100x slower), see tools/graph_pg_rehearsal.py.
         # MAVA_GRAPH_ROLLOUT=0 turns it off, =force keeps it on with several ranks.
         mode = os.environ.get("MAVA_GRAPH_ROLLOUT", "1")
-        self.graph_rollout = mode == "force" or (mode != "0" and self.world == 1)
+        self.graph_rollout = (mode == "force" or (mode != "0" and self.world == 1)) and not self.generic
         self._graphs: Dict[int, Any] = {}  # keyed by the seed: ONE graph for every update index n
         self._graph_seen: set = set()
         self.seed = int(s.seed)
@@ -165,7 +182,7 @@ class FFLearner:
         ops.lib().mava_ppo_set_matmul_mode(1 if self.matmul_mode == "f16x2" else 0)
         # the whole rollout in one launch (rollout_h2.hip) when the shape is instantiated; MAVA_FUSED_ROLLOUT=0 keeps
         # the per-step kernels
-        self.fused_rollout = (self.matmul_mode == "f16x2" and not self.continuous
+        self.fused_rollout = (self.matmul_mode == "f16x2" and not self.continuous and not self.generic
                               and os.environ.get("MAVA_FUSED_ROLLOUT", "1") != "0"
                               and int(getattr(env0, "synth_state_dim", 0)) == 0
                               and (not centralised_critic or (env0.gs_tiles == 1 and env0.global_state_shared)))
@@ -245,7 +262,7 @@ class FFLearner:
     def adopt(self, state: LearnerState) -> None:
         """Make the device buffers equal to `state` (no-op for leaves that already alias them), so that
         learn() is a function of its argument like the reference's pure learner_fn."""
-        pa = state.params.actor_params["params"]["torso"]["Dense_0"]["kernel"]
+        pa = self.actor_network.first_leaf(state.params.actor_params)
         if pa.data_ptr() != self.p.data_ptr():
             self.actor_network.flat_from_tree(state.params.actor_params, self.p[: self.Pa])
             self.critic_network.flat_from_tree(state.params.critic_params, self.p[self.Pa :])
@@ -335,7 +352,9 @@ class FFLearner:
                 common = dict(critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
                               value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
                               step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA)
-                if self.continuous:
+                if self.generic:
+                    self._timed("policy_step", self._generic_act, u, rep, t, step)
+                elif self.continuous:
                     self._timed("policy_step", ops.policy_step_continuous, pa, pc, av, cx, action_dim=self.nA,
                                 out=(rep.action[t].view(EA, self.nA), rep.log_prob[t].view(EA), rep.value[t].view(EA)),
                                 **common)
@@ -359,7 +378,12 @@ class FFLearner:
         EA = self.E * self.A
         for rep in self.reps:
             cx = rep.global_state[self.T].view(-1, self.Oc) if self.centralised else rep.agents_view[self.T].view(EA, self.Oa)
-            ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share, out=rep.last_val.view(EA, 1))
+            if self.generic:
+                v = self.critic_network.net.forward(pc, self._gws_roll[1], cx.view(1, self.E, -1, self.Oc), self.critic_share, None, EA,
+                                                    self.E, self.A)[0]
+                rep.last_val.view(EA).copy_(v)
+            else:
+                ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share, out=rep.last_val.view(EA, 1))
             self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
                         rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
                         out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
@@ -372,6 +396,9 @@ class FFLearner:
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         idx = None if perm is None else perm[mb * self.Rb : (mb + 1) * self.Rb]
         base = mb * self.Rb
+        if self.generic:
+            return self._minibatch_generic(n, k, mb, idx if idx is not None else torch.arange(base, base + self.Rb, dtype=torch.int32,
+                                                                                             device=self.device))
         # actor: gradient kernels of every replica, fixed-order slab sum into g[:Pa] (+ actor_loss, entropy)
         for u, rep in enumerate(self.reps):
             av = rep.agents_view[:T].view(TEA, self.Oa)
@@ -400,6 +427,96 @@ class FFLearner:
             if wk is not None:
                 wk.wait()
         self._timed("clip_adam", ops.clip_adam, self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
+                      grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
+                      decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
+                      num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),
+                      ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
+        self.ent_step += 1
+
+    # ---------------------------------------------------------------- general network path (mava_amd/generic_networks.py)
+    def _generic_setup(self) -> None:
+        d = self.device
+        EA, Rm = self.E * self.A, self.Rb * self.A
+        a, c = self.actor_network.net, self.critic_network.net
+        self._gws_roll = (a.workspace(EA, d, False), c.workspace(EA, d, False))
+        self._gws = (a.workspace(Rm, d, True), c.workspace(Rm, d, True))
+        # the backward chain runs in units of a power of two near the row count (mava_seq_actor_loss_f32: f16 range)
+        self._g_scale = float(2 ** math.ceil(math.log2(Rm)))
+        self._g_dscale = torch.zeros((self._gws[0].loss_partials.shape[0], max(self.nA, 1)), device=d)
+
+    def _generic_act(self, u: int, rep, t: int, step: int) -> None:
+        """ff_mappo.py:76-94 for one replica and step: actor forward -> sample / log-prob, critic forward -> value."""
+        if not hasattr(self, "_gws_roll"):
+            self._generic_setup()
+        L, st = ops.lib(), ops.stream_ptr()
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        E, A, EA = self.E, self.A, self.E * self.A
+        an = self.actor_network
+        outs = an.net.forward(pa, self._gws_roll[0], rep.agents_view[t : t + 1], 1, None, EA, E, A)
+        seed, row_off = self.seed & (2**64 - 1), ((self.rank * self.U + u) * EA) & 0xFFFFFFFF
+        gstep = (self.t_global + step) & 0xFFFFFFFF  # (the general path is not graph-captured: host-side step counter)
+        if self.continuous:
+            ind = an.independent_std
+            ops.check(L.mava_seq_sample_continuous_f32(EA, self.nA, ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
+                                                       None if ind else ops.ptr(outs[1]), seed, gstep, row_off, 0, ops.ptr(rep.action[t]),
+                                                       ops.ptr(rep.log_prob[t]), st), "mava_seq_sample_continuous_f32")
+        else:
+            ops.check(L.mava_seq_sample_f32(EA, self.nA, ops.ptr(outs[0]), ops.ptr(rep.action_mask[t]), seed, gstep, row_off, 0,
+                                            ops.ptr(rep.action[t]), ops.ptr(rep.log_prob[t]), st), "mava_seq_sample_f32")
+        cx = rep.global_state[t : t + 1] if self.centralised else rep.agents_view[t : t + 1]
+        v = self.critic_network.net.forward(pc, self._gws_roll[1], cx, self.critic_share, None, EA, E, A)[0]
+        rep.value[t].view(EA).copy_(v)  # a (rows x 1) T32 matrix is row-major
+
+    def _minibatch_generic(self, n: int, k: int, mb: int, idx: torch.Tensor) -> None:
+        """ff_mappo.py:144-266 on the general path: the (t, e) rows of the minibatch are presented to the sequence kernels
+        as T = 1 'sequences' over a flattened env axis of T*E entries (idx = their indices)."""
+        if not hasattr(self, "_gws"):
+            self._generic_setup()
+        s = self.config.system
+        T, E, A = self.T, self.E, self.A
+        TE, Rm = T * E, self.Rb * A
+        L, st = ops.lib(), ops.stream_ptr()
+        pa, pc = self.p[: self.Pa], self.p[self.Pa :]
+        idx = idx.contiguous()
+        wa, wc = self._gws
+        an, cn, gs = self.actor_network, self.critic_network, self._g_scale
+        nblk = wa.loss_partials.shape[0]
+        for u, rep in enumerate(self.reps):
+            acc = u > 0
+            outs = an.net.forward(pa, wa, rep.agents_view[:T].view(1, TE, A, self.Oa), 1, idx, Rm, TE, A)
+            ops.adv_stats(rep.adv.view(-1), idx, 0, self.Rb, A, out=self.stats)
+            if self.continuous:
+                ind = an.independent_std
+                ops.check(L.mava_seq_actor_loss_continuous_f32(
+                    1, Rm, TE, A, self.nA, ops.ptr(idx), ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
+                    None if ind else ops.ptr(outs[1]), ops.ptr(rep.action), ops.ptr(rep.log_prob), ops.ptr(rep.adv), ops.ptr(self.stats),
+                    self.stats.shape[0], float(s.clip_eps), float(s.ent_coef), self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF,
+                    ((self.rank * self.U + u) * TE * A) & 0xFFFFFFFF, gs, ops.ptr(wa.dout[0]), None if ind else ops.ptr(wa.dout[1]),
+                    ops.ptr(wa.loss_partials), ops.ptr(self._g_dscale), nblk, st), "mava_seq_actor_loss_continuous_f32")
+                if ind:
+                    ops.slab_reduce(self._g_dscale, self.nA, an.log_std(self.g[: self.Pa]), accumulate=acc)
+            else:
+                ops.check(L.mava_seq_actor_loss_f32(1, Rm, TE, A, self.nA, ops.ptr(idx), ops.ptr(outs[0]), ops.ptr(rep.action_mask[:T]),
+                                                    ops.ptr(rep.action), ops.ptr(rep.log_prob), ops.ptr(rep.adv), ops.ptr(self.stats),
+                                                    self.stats.shape[0], float(s.clip_eps), float(s.ent_coef), gs, ops.ptr(wa.dout[0]),
+                                                    ops.ptr(wa.loss_partials), nblk, st), "mava_seq_actor_loss_f32")
+            ops.slab_reduce(wa.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
+            an.net.backward(pa, wa, wa.dout[: len(an.net.heads)], self.g[: self.Pa], accumulate=acc, grad_scale=gs)
+        w_actor = parallel.allreduce_sum_async(self.g[: self.Pa])
+        for u, rep in enumerate(self.reps):
+            acc = u > 0
+            cx = (rep.global_state[:T].view(1, TE, -1, self.Oc) if self.centralised else rep.agents_view[:T].view(1, TE, A, self.Oa))
+            v = cn.net.forward(pc, wc, cx, self.critic_share, idx, Rm, TE, A)[0]
+            ops.check(L.mava_seq_critic_loss_f32(1, Rm, TE, A, 1, ops.ptr(idx), ops.ptr(v), ops.ptr(rep.value), ops.ptr(rep.tgt),
+                                                 float(s.clip_eps), float(s.vf_coef), gs, ops.ptr(wc.dout[0]), ops.ptr(wc.loss_partials),
+                                                 nblk, st), "mava_seq_critic_loss_f32")
+            ops.slab_reduce(wc.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
+            cn.net.backward(pc, wc, [wc.dout[0]], self.g[self.Pa : self.P], accumulate=acc, grad_scale=gs)
+        w_rest = parallel.allreduce_sum_async(self.g[self.Pa :])
+        for wk in (w_actor, w_rest):
+            if wk is not None:
+                wk.wait()
+        ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
                       num_updates=int(s.get("num_updates", 1) or 1), loss_sums=self.g[self.P :], vf_coef=float(s.vf_coef),

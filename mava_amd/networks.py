@@ -47,14 +47,16 @@ class DiscreteActionHead:
 
 
 class ContinuousActionHead:
-    """mava/networks.py:127-169: loc = Dense(action_dim), scale = softplus(log_std) + min_scale with an
-    observation-independent log_std parameter; actions in [-1, 1] through a tanh bijector."""
+    """mava/networks.py:127-169: loc = Dense(action_dim), scale = softplus(log_std) + min_scale; log_std is an
+    observation-independent parameter vector (independent_std=True, the fused kernels) or Dense(action_dim) of the
+    embedding (independent_std=False: the general network path, mava_amd/generic_networks.py); actions in [-1, 1]
+    through a tanh bijector."""
 
     def __init__(self, action_dim: int, min_scale: float = 1e-3, independent_std: bool = True, **_: Any):
         self.action_dim = int(action_dim)
-        if not independent_std or abs(float(min_scale) - 1e-3) > 1e-12:
-            raise NotImplementedError("mava_amd's kernels implement ContinuousActionHead(min_scale=1e-3, independent_std=True) "
-                                      f"(the reference's defaults); got min_scale={min_scale}, independent_std={independent_std}")
+        self.independent_std = bool(independent_std)
+        if abs(float(min_scale) - 1e-3) > 1e-12:
+            raise NotImplementedError(f"mava_amd's kernels implement ContinuousActionHead(min_scale=1e-3) (the reference's default); got {min_scale}")
         if self.action_dim > 16:
             raise NotImplementedError(f"continuous action heads are instantiated up to 16 dimensions, got {self.action_dim}")
 
@@ -102,6 +104,9 @@ def mlp_segments(din: int, n_out: int):
 class _FeedForwardNet:
     head_scale = 1.0
     head_parent = None  # name of the sub-module holding the head Dense
+
+    def first_leaf(self, tree: Dict[str, Any]) -> torch.Tensor:
+        return tree["params"]["torso"]["Dense_0"]["kernel"]
 
     def __init__(self, din: int, n_out: int):
         self.din, self.n_out = int(din), int(n_out)

@@ -23,7 +23,10 @@ from .synth_env import SynthRware
 class OracleLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, D=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95,
                  clip_eps=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4,
-                 decay=False, num_updates=1, time_limit=500, shared_gs=True, continuous=False, reward_mode="random"):
+                 decay=False, num_updates=1, time_limit=500, shared_gs=True, continuous=False, reward_mode="random",
+                 actor_spec=None, critic_spec=None, independent_std=True):
+        # actor_spec / critic_spec (oracle/generic_oracle.py): configurable torsos instead of the default [128, 128] MLP
+        self.actor_spec, self.critic_spec, self.independent_std = actor_spec, critic_spec, independent_std
         self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
         self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U, self.D = E, A, O, nA, T, K, M, U, D
@@ -52,26 +55,37 @@ class OracleLearner:
         """ff_mappo.py:76-106 for one (rank, replica)."""
         E, A, T, nA = self.E, self.A, self.T, self.nA
         env, obs = self.envs[d][u], self.obs[d][u]
-        pa, pc = po.mlp_unflatten(self.pa[: po.mlp_param_count(self.Oa, nA)], self.Oa, nA), po.mlp_unflatten(self.pc, self.Oc, 1)
+        if self.actor_spec is not None:
+            from . import generic_oracle as go
+
+            pa = pc = None
+            a_fwd = lambda x: go.np_forward(self.pa, self.actor_spec, x)
+            c_fwd = lambda x: go.np_forward(self.pc, self.critic_spec, x)[0]
+        else:
+            pa, pc = po.mlp_unflatten(self.pa[: po.mlp_param_count(self.Oa, nA)], self.Oa, nA), po.mlp_unflatten(self.pc, self.Oc, 1)
+            a_fwd = lambda x: [po.mlp_forward(pa, x)]
+            c_fwd = lambda x: po.mlp_forward(pc, x)
         tr = {k: [] for k in ("av", "cx", "mask", "action", "value", "reward", "log_prob", "done", "ret", "len", "term")}
         for t in range(T):
             step = self.t_global + t
             av = obs["agents_view"].astype(np.float64)
             cx = self._critic_in(obs)
             mask = obs["action_mask"]
-            y = po.mlp_forward(pa, av.reshape(E * A, -1))
+            outs = a_fwd(av.reshape(E * A, -1))
+            y = outs[0]
+            log_std = self.pa[-nA:] if self.independent_std else outs[1]
             if self.continuous:
                 eps = tn.normal_noise(self.seed, step, E * A, nA, tn.STREAM_SAMPLE, row_offset=(d * self.U + u) * E * A)
                 # the action is stored in float32 (the trajectory dtype) and scored as stored
-                action = tn.sample(y, self.pa[-nA:], eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
-                lp = tn.log_prob(action, y, self.pa[-nA:])
+                action = tn.sample(y, log_std, eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
+                lp = tn.log_prob(action, y, log_std)
                 action = action.reshape(E, A, nA)
             else:
                 z = po.masked_logits(y, mask.reshape(E * A, nA))
                 uni = philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=(d * self.U + u) * E * A)
                 action = po.gumbel_argmax(z, uni).reshape(E, A)
                 lp = po.log_softmax(z)[np.arange(E * A), action.reshape(-1)]
-            value = po.mlp_forward(pc, cx.reshape(E * A, -1))[:, 0]
+            value = c_fwd(cx.reshape(E * A, -1))[:, 0]
             obs, reward, done, info = env.step(step + 1, action=None if self.continuous else action)
             for k, v in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", value.reshape(E, A)),
                          ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done", done),
@@ -79,7 +93,7 @@ class OracleLearner:
                 tr[k].append(v)
         self.obs[d][u] = obs
         tr = {k: np.stack(v, 0) for k, v in tr.items()}
-        last_val = po.mlp_forward(pc, self._critic_in(obs).reshape(E * A, -1))[:, 0].reshape(E, A)  # ff_mappo.py:110
+        last_val = c_fwd(self._critic_in(obs).reshape(E * A, -1))[:, 0].reshape(E, A)  # ff_mappo.py:110
         tr["adv"], tr["tgt"] = po.gae(tr["reward"], tr["value"], tr["done"], last_val, self.h["gamma"], self.h["lam"])
         tr["last_val"] = last_val
         return tr
@@ -106,7 +120,23 @@ class OracleLearner:
                         tr = trajs[d][u]
                         sel = lambda x: flat(x)[rows]
                         R = rows.size * A
-                        if self.continuous:
+                        if self.actor_spec is not None:
+                            from . import generic_oracle as go
+
+                            if self.continuous:
+                                gid = (rows[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
+                                eps = tn.normal_noise(self.seed, self.ent_step, 0, nA, tn.STREAM_ENTROPY,
+                                                      row_offset=(d * self.U + u) * T * E * A, gid=gid).astype(np.float64)
+                                _, la, ent, g1 = go.actor_loss_grad_continuous(
+                                    self.pa, self.actor_spec, sel(tr["av"]).reshape(R, -1), sel(tr["action"]).reshape(R, nA),
+                                    sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R), h["clip"], h["ent"], eps,
+                                    self.independent_std)
+                            else:
+                                _, la, ent, g1 = go.actor_loss_grad(
+                                    self.pa, self.actor_spec, sel(tr["av"]).reshape(R, -1), sel(tr["mask"]).reshape(R, nA),
+                                    sel(tr["action"]).reshape(R), sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R),
+                                    h["clip"], h["ent"])
+                        elif self.continuous:
                             gid = (rows[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)  # trajectory rows
                             eps = tn.normal_noise(self.seed, self.ent_step, 0, nA, tn.STREAM_ENTROPY,
                                                   row_offset=(d * self.U + u) * T * E * A, gid=gid).astype(np.float64)
@@ -118,9 +148,13 @@ class OracleLearner:
                                 self.pa, self.Oa, nA, sel(tr["av"]).reshape(R, -1), sel(tr["mask"]).reshape(R, nA),
                                 sel(tr["action"]).reshape(R), sel(tr["log_prob"]).reshape(R), sel(tr["adv"]).reshape(R),
                                 h["clip"], h["ent"])
-                        _, vl, g2 = po.critic_loss_and_grad(
-                            self.pc, self.Oc, sel(tr["cx"]).reshape(R, -1), sel(tr["value"]).reshape(R),
-                            sel(tr["tgt"]).reshape(R), h["clip"], h["vf"])
+                        if self.critic_spec is not None:
+                            _, vl, g2 = go.critic_loss_grad(self.pc, self.critic_spec, sel(tr["cx"]).reshape(R, -1),
+                                                            sel(tr["value"]).reshape(R), sel(tr["tgt"]).reshape(R), h["clip"], h["vf"])
+                        else:
+                            _, vl, g2 = po.critic_loss_and_grad(
+                                self.pc, self.Oc, sel(tr["cx"]).reshape(R, -1), sel(tr["value"]).reshape(R),
+                                sel(tr["tgt"]).reshape(R), h["clip"], h["vf"])
                         ga += g1
                         gc += g2
                         info += np.array([la, ent, vl])

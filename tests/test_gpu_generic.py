@@ -181,3 +181,103 @@ def test_generic_continuous_head(dev, independent, mode):
     if not independent:
         hd = net.heads[1]
         assert_close(gw_d.cpu().numpy()[hd.w : hd.w + hd.K * hd.N], gw[hd.w : hd.w + hd.K * hd.N], 1e-4, "log_std head kernel grad")
+
+
+E2E = [
+    ("ff_mappo", dict(kind="mlp", sizes=[64, 96], act="tanh", ln=True), False, True),
+    ("ff_ippo", dict(kind="cnn", shape=(2, 4, 2), channels=[8, 8], kernels=[3, 3], strides=[1, 1], act="relu", ln=False), False, True),
+    ("ff_ippo", dict(kind="mlp", sizes=[128, 128], act="relu", ln=False), True, False),  # state-dependent log_std head
+]
+
+
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
+@pytest.mark.parametrize("system,case,continuous,independent", E2E,
+                         ids=["mappo-mlp-tanh-ln", "ippo-cnn", "ippo-continuous-dependent-std"])
+def test_generic_learner_update_matches_oracle(dev, system, case, continuous, independent, matmul, monkeypatch):
+    """ff_ippo / ff_mappo with a non-default network configuration: the whole update (rollout, GAE, epochs x minibatches,
+    Adam) of the layer-wise path against the whole-update oracle on identical inputs, through the LearnerFn boundary."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import ff_ippo, ff_mappo
+    from oracle.ppo_loop import OracleLearner
+    from tests.conftest import check_and_sync_f16x2_state
+
+    monkeypatch.setenv("MAVA_MATMUL", matmul)
+    E, A, O, nA, T, K, M, U = 16, 4, 12, 5, 8, 2, 2, 1
+    dim = 3
+    central = system == "ff_mappo"
+    over = [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}", f"system.num_minibatches={M}",
+            f"system.update_batch_size={U}", "env/scenario=tiny-4ag"]
+    if continuous:
+        over.append("network.action_head._target_=mava.networks.ContinuousActionHead")
+    cfg = compose(f"default_{system}", over)
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": dim if continuous else nA}
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    if continuous and not independent:
+        cfg.network.action_head.independent_std = False
+    Oa, Oc = A + O, (A * O if central else A + O)
+    n_act = dim if continuous else nA
+    heads_a = [n_act] + ([n_act] if (continuous and not independent) else [])
+    tail = n_act if (continuous and independent) else 0
+    for netcfg in (cfg.network.actor_network.pre_torso, cfg.network.critic_network.pre_torso):
+        if case["kind"] == "cnn":
+            netcfg._target_ = "mava.networks.CNNTorso"
+            for k_ in ("layer_sizes",):
+                if k_ in netcfg:
+                    del netcfg[k_]
+            netcfg.channel_sizes, netcfg.kernel_sizes, netcfg.strides = case["channels"], case["kernels"], case["strides"]
+        else:
+            netcfg.layer_sizes = case["sizes"]
+        netcfg.activation, netcfg.use_layer_norm = case["act"], case["ln"]
+    if case["kind"] == "cnn":
+        assert int(np.prod(case["shape"])) == Oa
+        cfg.env.synthetic["obs_shape"] = list(case["shape"])
+        spec_a = go.spec_cnn(case["shape"], case["channels"], case["kernels"], case["strides"], heads_a, case["act"], case["ln"], tail)
+        spec_c = go.spec_cnn(case["shape"], case["channels"], case["kernels"], case["strides"], [1], case["act"], case["ln"])
+    else:
+        spec_a = go.spec_mlp(Oa, case["sizes"], heads_a, case["act"], case["ln"], tail)
+        spec_c = go.spec_mlp(Oc, case["sizes"], [1], case["act"], case["ln"])
+    mod = ff_mappo if central else ff_ippo
+    env, _ = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    assert L.generic and L.Pa == go.param_count(spec_a) and L.Pc == go.param_count(spec_c)
+    first = actor_network.net.layers[0]
+    leaf = state.params.actor_params["params"]["torso"][first.name]["kernel"]
+    assert leaf.shape[:2] == (1, U) and int(np.prod(leaf.shape[2:])) == first.K * first.N
+
+    rng = np.random.default_rng(0)
+    fa, fc = go.init(rng, spec_a).astype(np.float32), go.init(rng, spec_c).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleLearner(E=E, A=A, O=O, nA=n_act, T=T, K=K, M=M, U=U, D=1, centralised=central, seed=42, actor_lr=1e-3, critic_lr=2e-3,
+                        continuous=continuous, actor_spec=spec_a, critic_spec=spec_c, independent_std=independent)
+    ora.set_params(fa, fc)
+    ftol = 1e-5 if matmul == "f32" else 5e-5
+    for n in range(2):
+        perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        rep, tr = L.reps[0], ora.last_traj[0][0]
+        if continuous:
+            assert_close(rep.action.cpu().numpy(), tr["action"], 1e-5 if matmul == "f32" else 1e-4, "actions", scale=1.0)
+        else:
+            assert np.array_equal(rep.action.cpu().numpy(), tr["action"]), "sampled actions differ"
+        assert_close(rep.value.cpu().numpy(), tr["value"], ftol, "values")
+        assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-4 if continuous else ftol, "log_probs", scale=1.0)
+        assert_close(rep.adv.cpu().numpy(), tr["adv"], ftol, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        if matmul == "f32":
+            assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+            assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        else:
+            check_and_sync_f16x2_state(L, ora)
+    out = learn(L.learner_state())  # the LearnerFn round trip (adopt -> updates -> state)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()
+    # the evaluator seam: actor_network.apply(params, observation) -> distribution
+    obs = out.learner_state.timestep.observation
+    dist = actor_network.apply(out.learner_state.params.actor_params, type(obs)(*[None if v is None else v[0, 0] for v in obs]))
+    assert dist.mode().shape[:2] == (E, A)

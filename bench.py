@@ -404,22 +404,29 @@ def main() -> None:
         by = {"gru_scan_fwd": 1536 + 1 + 512 + 2048 + 512, "gru_scan_bwd": 2048 + 512 + 512 + 1536 + 1536}[dom] * rows_avg
         t_s = avg[dom_key] * 1e-3
         tf, gbs = flop / t_s / 1e12, by / t_s / 1e9
-        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tf / F32_MFMA_PEAK_TFLOPS
-        rec_traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_rec_v5_pmc.json")) as f:
-                rec_traffic = (json.load(f).get("kernels", {}).get(f"{dom}_kernel grid={min(256, seqs // 32)}", {})
-                               .get("hbm_bytes_corrected")) if (seqs == 8192 and T == 128) else None
-        except (OSError, ValueError, KeyError):
-            pass
+        # the matrix peak of the arithmetic the scan runs in: exact-f32 MFMAs, or three f16 MFMAs per product (f16x2)
+        mfma_peak = F16X2_PEAK_TFLOPS if args.matmul == "f16x2" else F32_MFMA_PEAK_TFLOPS
+        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tf / mfma_peak
+        rec_traffic, rec_src = None, None
+        kname = f"{dom}_h2_kernel" if args.matmul == "f16x2" else f"{dom}_kernel"
+        for fname in ("r02_rec_pmc_traffic.json", "r01_rec_v5_pmc.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    rec_traffic = (json.load(f).get("kernels", {}).get(f"{kname} grid={min(256, seqs // 32)}", {})
+                                   .get("hbm_bytes_corrected")) if (seqs == 8192 and T == 128) else None
+            except (OSError, ValueError, KeyError):
+                rec_traffic = None
+            if rec_traffic:
+                rec_src = f"profiles/{fname} (committed PMC pass, not measured in this run)"
+                break
         if hbm_frac >= mfma_frac:
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": hbm_frac, "traffic": rec_traffic, "mfma_frac": mfma_frac}
         else:
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": tf, "peak": mfma_peak,
                                "unit": "TFLOP/s", "frac": mfma_frac, "traffic": rec_traffic, "hbm_frac": hbm_frac}
         out["roofline"].update({"avg_launch_ms": avg[dom_key], "row_steps_per_launch": rows_avg,
-                                "traffic_source": "profiles/r01_rec_v5_pmc.json (committed PMC pass)" if rec_traffic else None})
+                                "traffic_source": rec_src})
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.system.startswith("rec") and not continuous:
         from oracle import rec_cpu_loop

@@ -16,4 +16,4 @@ void mava_set_error(const char* fmt, ...) {
 
 extern "C" const char* mava_last_error(void) { return g_err; }
 
-extern "C" int mava_abi_version(void) { return 1; }
+extern "C" int mava_abi_version(void) { return 2; }  // 2: round-2 signatures (grad_scale, y_ld, packed acting step, comm, general layers)

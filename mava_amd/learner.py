@@ -152,7 +152,13 @@ class FFLearner:
 
         self.Rb = self.T * self.E // self.M  # env rows per minibatch
         ntiles = (self.Rb * self.A + 31) // 32
-        self.n_slab = max(1, min(NUM_CU, ntiles))
+        # The gradient kernels are persistent blocks that own a CU each (all of its registers and LDS): with several ranks
+        # a few CUs stay free of them, so that RCCL's all-reduce kernel of the actor's slice can really run WHILE the
+        # critic's gradient kernel does (parallel.allreduce_sum_async below); system.rccl_cus / MAVA_RCCL_CUS, default 8
+        # with a process group (a ~0.3 MB message uses a handful of channels), 0 on a single rank.
+        self.rccl_cus = int(s.get("rccl_cus", None) if s.get("rccl_cus", None) is not None
+                            else os.environ.get("MAVA_RCCL_CUS", "8" if self.world > 1 else "0"))
+        self.n_slab = max(1, min(NUM_CU - max(0, min(self.rccl_cus, NUM_CU - 1)), ntiles))
         self.slab_a = torch.zeros((self.n_slab, self.Pa + 2), device=d)
         self.slab_c = torch.zeros((self.n_slab, self.Pc + 2), device=d)
         self.stats = torch.zeros((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)

@@ -149,7 +149,10 @@ class RecLearner:
         # f16x2: both networks' weights pre-split in MFMA-fragment order for the fused acting step (re-packed per rollout)
         self.pack_a = torch.empty(lib().mava_rec_step_pack_bytes(self.Oa), dtype=torch.uint8, device=d)
         self.pack_c = torch.empty(lib().mava_rec_step_pack_bytes(self.Oc), dtype=torch.uint8, device=d)
-        n_slab = max(1, min(NUM_CU, (self.T * self.Rm) // 32))
+        # (with several ranks a few CUs stay free of the persistent X^T Y blocks for RCCL's kernels: learner.py)
+        self.rccl_cus = int(s.get("rccl_cus", None) if s.get("rccl_cus", None) is not None
+                            else os.environ.get("MAVA_RCCL_CUS", "8" if self.world > 1 else "0"))
+        n_slab = max(1, min(NUM_CU - max(0, min(self.rccl_cus, NUM_CU - 1)), (self.T * self.Rm) // 32))
         self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 14
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in mava_hip.h but not exported by libmavahip.so"
-    assert lib.mava_abi_version() == 1
+    assert lib.mava_abi_version() == 2
 
 
 def test_python_binding_matches_header():

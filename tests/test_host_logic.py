@@ -35,8 +35,17 @@ def test_overrides():
     assert isinstance(make_action_head(compose("default_ff_mappo", ["network=continuous_mlp"]).network.action_head, 3),
                       ContinuousActionHead)
     assert isinstance(make_action_head(c.network.action_head, 5), DiscreteActionHead)
+    assert ContinuousActionHead(3, independent_std=False).independent_std is False  # (runs on the general network path)
     with pytest.raises(NotImplementedError):
-        ContinuousActionHead(3, independent_std=False)
+        ContinuousActionHead(3, min_scale=1e-2)
+    # network group swap to the CNN torsos (configs/network/cnn.yaml) and the general path's selection rule
+    from mava_amd.generic_networks import CNNTorso, is_default_mlp, torso_from_config
+
+    cnn = compose("default_ff_ippo", ["network=cnn"]).network
+    assert isinstance(torso_from_config(cnn.actor_network.pre_torso), CNNTorso) and not is_default_mlp(cnn.actor_network.pre_torso)
+    assert is_default_mlp(c.network.actor_network.pre_torso)
+    ln = compose("default_ff_ippo", ["network.actor_network.pre_torso.use_layer_norm=true"]).network
+    assert not is_default_mlp(ln.actor_network.pre_torso)
 
 
 def test_total_timesteps():

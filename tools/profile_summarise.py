@@ -13,7 +13,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("ppo_train", "rollout_h2", "gae_kernel", "clip_adam", "slab_reduce", "adv_stats", "policy_", "synth_rware", "mlp_forward",
-        "pack_w1", "gru_scan", "rec_dense", "rec_xty", "seq_", "rec_step", "t32_convert", "coop")
+        "pack_w1", "gru_scan", "rec_dense", "rec_xty", "seq_", "rec_step", "t32_convert", "coop", "rec_gather", "rec_pack",
+        "norm_act", "colsum", "im2col", "col2im", "flatten_kernel")
 
 
 def short(name: str) -> str:
@@ -33,7 +34,13 @@ def counters(d):
     if not f:
         return out
     for row in csv.DictReader(open(f)):
-        out[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = short(row["Kernel_Name"])
+        out[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        try:  # the same kernel at different grids (actor: 256 blocks, the once-per-env critic: 32) also per grid
+            blocks = int(row["Grid_Size"]) // max(1, int(row["Workgroup_Size"]))
+            out[f"{name} grid={blocks}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        except (KeyError, ValueError):
+            pass
     return out
 
 

@@ -334,17 +334,22 @@ def test_rec_learner_update_matches_oracle(dev, system, U, E, matmul):
     assert out.train_metrics["total_loss"].shape == (1, 2, U, K, M) and torch.isfinite(out.train_metrics["total_loss"]).all()
 
 
-def test_rec_dense_rejects_unsupported_t32_width(dev):
-    """T32 inputs wider than 32 features must be a multiple of 16 (internal widths are 128/384/n_out): loud error."""
-    from mava_amd._lib import MavaHipError, check, lib, ptr, stream_ptr
+def test_rec_dense_any_t32_width(dev, rec_mode):
+    """T32 inputs of any width (155 = the config-4 observation; the general network path produces arbitrary layer sizes):
+    clamped operand addresses in the exact-f32 kernel, staged zeros in the f16x2 kernel."""
+    from mava_amd._lib import check, lib, ptr, stream_ptr
 
-    lib().mava_ppo_set_matmul_mode(0)  # (the f16x2 kernel stages any width; this is the exact-f32 kernel's restriction)
-    x = torch.zeros(32 * 155, device=dev)
-    w = torch.zeros(155 * 128, device=dev)
-    y = torch.zeros(32 * 128, device=dev)
-    with pytest.raises(MavaHipError):
-        check(lib().mava_rec_dense_f32(ptr(x), 0, None, 0, 0, 0, 1, 155, 0, ptr(w), 128, None, None, ptr(y), 0, 155, 128, 32, 0,
+    rng = np.random.default_rng(155)
+    for K, N in ((155, 128), (100, 96), (37, 13)):
+        rows = 64
+        x = rng.standard_normal((rows, K)).astype(np.float32)
+        w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+        xt, wt = _t(_to_t32(x), dev), _t(w, dev)
+        y = torch.zeros(rows * N, device=dev)
+        check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, None, None, ptr(y), 0, K, N, rows, 0,
                                        stream_ptr()), "dense")
+        torch.cuda.synchronize()
+        assert_close(_from_t32(y.cpu().numpy(), rows, N), x.astype(np.float64) @ w.astype(np.float64), 1e-5, f"dense K={K} N={N}")
 
 
 def test_recurrent_apply_and_eval_act_fn(dev):

@@ -879,6 +879,8 @@ int dispatch_s1(const TrainTask& tk, int n_slab, hipStream_t s) {
     case 6: return dispatch_xv<NO, 6, ACTOR, false>(tk, n_slab, s);
     case 7: case 8: case 9: case 10: case 11: case 12: return dispatch_xv<NO, 12, ACTOR, true>(tk, n_slab, s);
 #endif
+    // (the role-split 512-thread form was also measured for this narrow input: actor 0.94 instead of 0.70 ms per launch -
+    // the resident W1 fragments and one barrier set per tile beat the second wave group here)
     case 5: return dispatch_xv<NO, 5, ACTOR, false>(tk, n_slab, s);
     case 13: case 14: case 15: case 16: case 17: case 18: return dispatch_xv<NO, 18, ACTOR, true>(tk, n_slab, s);
     default: return 1;  // not instantiated (input width > 287): the caller runs the exact-f32 kernel

@@ -180,7 +180,12 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   // steps resident; WIDE: a ring of W1_RING steps fed from the pre-split global copy.
   constexpr int NW1 = !CHAIN ? 1 : (WIDE ? W1_RING : S1);
   Frag W1f[NW1];
-  const uint4* const w1p_lane = w1p + 2 * (w * 64 + lane);  // + 2 * 256 * s
+  // The fragment of step s sits 8 KB x s behind this lane's base: too far for an instruction immediate.  Written against a
+  // loop-invariant base the compiler forms one 64-bit address per step, hoists all of them out of the tile loop and spills
+  // them - and every reload (scratch shares vmcnt with the ring's loads) drains the ring: the wide critic spent 513 cycles
+  // per step on 96 cycles of matrix work.  A base made opaque once per tile keeps the per-step addresses inside the loop:
+  // two adds from a live register.
+  const uint4* w1p_lane = w1p + 2 * (w * 64 + lane);  // + 2 * 256 * s
   auto w1_fetch = [&](int s) -> Frag {
     Frag f;
     f.hi = __builtin_bit_cast(half8, w1p_lane[512 * s]);
@@ -423,6 +428,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x16 acc;
     uint32_t relu1 = 0;
+    if constexpr (WIDE && CHAIN) asm volatile("" : "+v"(w1p_lane));  // (see w1_fetch: its addresses stay loop-variant)
     if constexpr (CHAIN) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;

@@ -287,6 +287,18 @@ int mava_seq_critic_loss_f32(int T, int Rm, int E, int A, int agents_per_row, co
                              const float* old_value, const float* targets, float clip_eps, float vf_coef,
                              float grad_scale, float* dvalues, float* loss_partials, int n_blocks, mava_stream_t s);
 
+/* The OUTPUT PATH of a recurrent network in one launch on split-f16 operands (rec_out_h2.hip): post_torso -> head ->
+ * PPO loss (rec_mappo.py:210-242 actor / :244-266 critic) -> backward through both layers.  hs: T32 (T*Rm x 128) hidden
+ * states; params_post_head: [Wpost | bpost | Whead | bhead] (the tail of the flat parameters); is_actor: f0 / f1 =
+ * old_log_prob / advantages (+ mask, action, adv_stats), else old_value / targets with agents_per_row as in
+ * mava_seq_critic_loss_f32.  Writes dh (T32, d loss / d hs TIMES grad_scale) and per-block slabs [dWpost | dbpost | dWhead |
+ * dbhead | loss sums (2)] in true units.  Returns 1 (nothing launched) for shapes it does not instantiate: more than 16
+ * outputs, n_slab > tiles - the caller then runs the layer-wise kernels. */
+int mava_rec_out_f32(int T, int Rm, int E, int A, int n_out, int agents_per_row, const int32_t* idx, const float* hs,
+                     const float* params_post_head, const uint8_t* mask, const int32_t* action, const float* f0,
+                     const float* f1, const double* adv_stats, int n_stats, float clip_eps, float coef, float grad_scale,
+                     int is_actor, float* dh, float* slab, long slab_stride, int n_slab, mava_stream_t s);
+
 /* rollout epilogue: masked Categorical sample + log_prob from T32 logits of one step (rows = E*A). */
 int mava_seq_sample_f32(int rows, int n_actions, const float* logits, const uint8_t* mask, uint64_t seed,
                         uint32_t step, uint32_t row_offset, int greedy, int32_t* action, float* log_prob,

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "mava_rec_step_f32": [vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp,
                           i32, i32, vp, vp],
     "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
+    "mava_rec_out_f32": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, lng, i32, vp],
     "mava_rec_step_pack_bytes": [i32],
     "mava_t32_norm_act_f32": [vp, i32, lng, i32, vp, i32, vp, vp, vp, vp],
     "mava_t32_norm_act_bwd_f32": [vp, vp, i32, lng, i32, vp, vp, i32, vp, vp, vp],
@@ -128,17 +129,20 @@ def check(rc: int, what: str) -> None:
 TIMERS: Optional[dict] = None
 
 
-def launch(what: str, fn, *args) -> None:
-    """check(fn(*args), what), optionally timed with HIP events on the launch stream."""
+def launch(what: str, fn, *args, ok=(0,)) -> int:
+    """check(fn(*args), what), optionally timed with HIP events on the launch stream.  Return codes listed in `ok` are
+    passed back to the caller instead of raising (1 = "shape not instantiated" of the optional fused kernels)."""
     if TIMERS is None:
-        check(fn(*args), what)
-        return
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    rc = fn(*args)
-    b.record()
-    TIMERS.setdefault(what, []).append((a, b))
-    check(rc, what)
+        rc = fn(*args)
+    else:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        TIMERS.setdefault(what, []).append((a, b))
+    if rc not in ok:
+        check(rc, what)
+    return rc
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -31,6 +31,7 @@ HIP_SOURCES = [
     "rec_gru_h2.hip",
     "rec_step.hip",
     "rec_step_h2.hip",
+    "rec_out_h2.hip",
     "generic_layers.hip",
 ]
 CPP_SOURCES = ["api.cpp", "comm.cpp"]

@@ -147,6 +147,8 @@ class RecLearner:
         # the backward chain runs in units of a power of two near the row count (mava_seq_actor_loss_f32: f16 range)
         self.grad_scale = float(2 ** math.ceil(math.log2(self.T * self.Rm)))
         # f16x2: both networks' weights pre-split in MFMA-fragment order for the fused acting step (re-packed per rollout)
+        self.fused_out = (self.matmul_mode == "f16x2" and not self.continuous and self.nA <= 16
+                          and os.environ.get("MAVA_REC_FUSED_OUT", "1") != "0")
         self.pack_a = torch.empty(lib().mava_rec_step_pack_bytes(self.Oa), dtype=torch.uint8, device=d)
         self.pack_c = torch.empty(lib().mava_rec_step_pack_bytes(self.Oc), dtype=torch.uint8, device=d)
         # (with several ranks a few CUs stay free of the persistent X^T Y blocks for RCCL's kernels: learner.py)
@@ -333,13 +335,21 @@ class RecLearner:
         flat_rows = (self._t_range + idx[None, :].long()).reshape(-1).to(torch.int32)  # (t*E + env) rows of the minibatch
         ws, L, st = self.ws, lib(), stream_ptr()
         nblk = ws.loss_partials.shape[0]
+        # f16x2: the output path (post_torso -> head -> loss -> backward) of both networks runs as ONE launch each
+        # (mava_rec_out_f32); the continuous head and more than 16 actions stay on the layer-wise kernels
+        fused_out = self.fused_out
         for u, rep in enumerate(self.reps):
             acc = u > 0
             # ---- actor (rec_mappo.py:210-242)
             self.actor_network.forward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, rep.h0_actor, False, idx, T, Rm, E, A,
-                                                training=True)
+                                                training=True, stop_after_scan=fused_out)
             ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
-            if self.continuous:
+            if fused_out:
+                ok = self.actor_network.fused_output(pa, ws, idx, T, Rm, E, A, 1, True, rep.action_mask[:T], rep.action, rep.log_prob,
+                                                     rep.adv, self.stats, float(s.clip_eps), float(s.ent_coef), self.slabs,
+                                                     self.g[: self.Pa], self.g[self.P : self.P + 2], acc, self.grad_scale)
+                assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
+            elif self.continuous:
                 check(L.mava_seq_actor_loss_continuous_f32(
                     T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
                     ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
@@ -352,9 +362,10 @@ class RecLearner:
                                                 float(s.clip_eps), float(s.ent_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
                                                 nblk, st),
                       "mava_seq_actor_loss_f32")
-            ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
+            if not fused_out:
+                ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
             self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, self.slabs,
-                                                 self.g[: self.Pa], accumulate=acc, grad_scale=self.grad_scale)
+                                                 self.g[: self.Pa], accumulate=acc, grad_scale=self.grad_scale, from_scan=fused_out)
             # ---- critic (rec_mappo.py:244-266)
             cx = self._critic_x(rep, 0, T)
             if self.critic_agg:  # E-row sequences: kernel view (E envs x 1 "agent"), A agent slots per row in the loss
@@ -362,14 +373,21 @@ class RecLearner:
             else:
                 c_share, c_done, c_Rm, c_A, c_apr = self.critic_share, rep.done_in, Rm, A, 1
             self.critic_network.forward_sequence(pc, ws, cx, c_share, c_done, rep.h0_critic, False, idx, T, c_Rm, E, c_A,
-                                                 training=True)
-            check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
-                                             float(s.clip_eps), float(s.vf_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
-                                             nblk, st),
-                  "mava_seq_critic_loss_f32")
-            ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
+                                                 training=True, stop_after_scan=fused_out)
+            if fused_out:
+                ok = self.critic_network.fused_output(pc, ws, idx, T, c_Rm, E, c_A, c_apr, False, None, None, rep.value, rep.tgt, None,
+                                                      float(s.clip_eps), float(s.vf_coef), self.slabs, self.g[self.Pa : self.P],
+                                                      self.g[self.P + 2 : self.P + 3], acc, self.grad_scale)
+                assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
+            else:
+              check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
+                                               float(s.clip_eps), float(s.vf_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
+                                               nblk, st),
+                    "mava_seq_critic_loss_f32")
+              ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
             self.critic_network.backward_sequence(pc, ws, cx, c_share, c_done, idx, T, c_Rm, E, c_A, self.slabs,
-                                                  self.g[self.Pa : self.P], accumulate=acc, grad_scale=self.grad_scale)
+                                                  self.g[self.Pa : self.P], accumulate=acc, grad_scale=self.grad_scale,
+                                                  from_scan=fused_out)
         parallel.allreduce_sum_(self.g)
         ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),

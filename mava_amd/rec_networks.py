@@ -161,7 +161,7 @@ class _RecurrentNet:
 
     # ------------------------------------------------------------------------------------- kernels
     def forward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, h0, h0_t32, idx, T, Rm, E, A,
-                         training: bool, y_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         training: bool, y_out: Optional[torch.Tensor] = None, stop_after_scan: bool = False) -> torch.Tensor:
         """Runs the network over a time-major sequence batch; returns T32 outputs (ws.y).  x_ext is the external
         row-major (T, E, A/x_share.., din) tensor, done_ext (T, E, A) u8 the flags entering each step."""
         rows = T * Rm
@@ -191,6 +191,8 @@ class _RecurrentNet:
                G3, rows, 0, s)
         launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
                ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
+        if stop_after_scan:  # the output path runs fused (fused_output)
+            return ws.hs
         launch("rec_dense(post)", L.mava_rec_dense_f32, ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None,
                ptr(ws.post), 0, H, H, rows, 1, s)
         y = ws.y if y_out is None else y_out
@@ -198,8 +200,24 @@ class _RecurrentNet:
                None, ptr(y), 0, H, self.n_out, rows, 0, s)
         return y
 
+    def fused_output(self, flat, ws: RecWorkspace, idx, T, Rm, E, A, agents_per_row, is_actor: bool, mask, action, f0, f1, stats,
+                     clip_eps: float, coef: float, slabs, grad_out, loss_out, accumulate: bool, grad_scale: float) -> bool:
+        """post_torso -> head -> loss -> backward to ws.dh_out plus the gradients of both layers in ONE launch
+        (mava_rec_out_f32, csrc/rec_out_h2.hip).  False when the library does not instantiate the shape."""
+        n_out = self.n_out
+        o = self.off["Wpost"][0]
+        n_main = H * H + H + H * n_out + n_out
+        slabs = slabs[: max(1, min(slabs.shape[0], (T * Rm) // 32))]  # every block owns a tile (the once-per-env critic has fewer)
+        rc = launch("rec_out", lib().mava_rec_out_f32, T, Rm, E, A, n_out, agents_per_row, ptr(idx), ptr(ws.hs), flat.data_ptr() + 4 * o,
+                    ptr(mask), ptr(action), ptr(f0), ptr(f1), ptr(stats), 0 if stats is None else stats.shape[0], clip_eps, coef,
+                    grad_scale, int(is_actor), ptr(ws.dh_out), ptr(slabs), slabs.shape[1], slabs.shape[0], stream_ptr(), ok=(0, 1))
+        if rc == 1:
+            return False
+        ops.slab_reduce2(slabs, n_main, grad_out[o : o + n_main], loss_out.numel(), loss_out, accumulate=accumulate)
+        return True
+
     def backward_sequence(self, flat, ws: RecWorkspace, x_ext, x_share, done_ext, idx, T, Rm, E, A, slabs, grad_out,
-                          accumulate: bool, grad_scale: float = 1.0) -> None:
+                          accumulate: bool, grad_scale: float = 1.0, from_scan: bool = False) -> None:
         """BPTT from ws.dy (T32 d loss / d outputs, in units of `grad_scale`: a power of two, see
         mava_seq_actor_loss_f32) to the flat gradient `grad_out` (same layout as `flat`, true units)."""
         rows = T * Rm
@@ -213,8 +231,9 @@ class _RecurrentNet:
         d = lambda k, N, x, w, ldw, gate, y: launch(
             "rec_dense(bwd)", L.mava_rec_dense_f32, ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), 0, k, N,
             rows, 0, s)
-        d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
-        d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
+        if not from_scan:  # (from_scan: fused_output already left ws.dh_out and the output path's gradients)
+            d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
+            d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
         launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved),
                ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
         d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
@@ -229,8 +248,9 @@ class _RecurrentNet:
                 ops.slab_reduce(tail, nb, grad_out[b_off : b_off + nb], accumulate=accumulate)
 
         o = lambda n: self.off[n][0]
-        xty(ptr(ws.post), 0, H, H, n_out, ws.dy, o("Whead"), o("bhead"), n_out)
-        xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
+        if not from_scan:
+            xty(ptr(ws.post), 0, H, H, n_out, ws.dy, o("Whead"), o("bhead"), n_out)
+            xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
         xty(ptr(ws.xpre), 0, H, H, G3, ws.dgi, o("Wi"), o("bi"), G3)
         xty(ptr(ws.hprev), 0, H, H, G3, ws.dgh, o("Wh"), o("bhn"), H, bias_slice=2 * H)  # db_hn: n-part of colsum(dgh)
         t32_in = ws.xin is not None and L.mava_ppo_get_matmul_mode() == 1  # the forward pass left the gathered input in ws.xin

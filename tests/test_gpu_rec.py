@@ -194,9 +194,13 @@ def xty_variant(request):
 # (128, 8, 8, 4, 155, 13): BPTT over the FULL sequence length of BASELINE config 4 (seq_len = 128, 8 agents, input 155,
 # 13 actions) - actor and critic gradients at the north-star 1e-4 against float64 autograd
 @pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13), (128, 8, 8, 4, 155, 13)])
-def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant, rec_mode):
+@pytest.mark.parametrize("fused_out", [False, True], ids=["layerwise-out", "fused-out"])
+def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant, rec_mode, fused_out):
+    """fused_out: post_torso -> head -> loss -> backward in one launch (mava_rec_out_f32) instead of eight."""
     if xty_variant == 1 and rec_mode == 1:
         pytest.skip("the bf16x6 X^T Y variant is an alternative to the f16x2 arithmetic, not a combination")
+    if fused_out and (rec_mode == 0 or xty_variant == 1):
+        pytest.skip("the fused output path belongs to the f16x2 arithmetic")
     from mava_amd import ops
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd.networks import DiscreteActionHead, MLPTorso
@@ -233,36 +237,49 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_varia
     slabs = torch.zeros((4, 128 * 384 + 384 + 8), device=dev)
     # ---- actor
     fa_d = d(fa)
-    actor.forward_sequence(fa_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
+    actor.forward_sequence(fa_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True, stop_after_scan=fused_out)
     flat_rows = (torch.arange(T, device=dev)[:, None] * E + idx_d[None, :].long()).reshape(-1).to(torch.int32)
     adv_d, mask_d, act_d, olp_d = d(adv), d(mask).view(torch.uint8), d(action), d(old_lp)  # kept alive (see above)
     stats = ops.adv_stats(adv_d.view(-1), flat_rows, 0, T * Em, A)
-    check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(mask_d), ptr(act_d),
-                                        ptr(olp_d), ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, gscale, ptr(ws.dy),
-                                        ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "actor loss")
     ga = torch.zeros(actor.num_params, device=dev)
-    actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False, grad_scale=gscale)
+    lsum_d = torch.zeros(2, device=dev)
+    if fused_out:
+        assert actor.fused_output(fa_d, ws, idx_d, T, Rm, E, A, 1, True, mask_d, act_d, olp_d, adv_d, stats, 0.2, 0.01, slabs, ga,
+                                  lsum_d, False, gscale)
+    else:
+        check(lib().mava_seq_actor_loss_f32(T, Rm, E, A, nA, ptr(idx_d), ptr(ws.y), ptr(mask_d), ptr(act_d),
+                                            ptr(olp_d), ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, gscale, ptr(ws.dy),
+                                            ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "actor loss")
+    actor.backward_sequence(fa_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, ga, accumulate=False, grad_scale=gscale,
+                            from_scan=fused_out)
     torch.cuda.synchronize()
     tot, la, ent, g = ro.rec_actor_loss_grad(fa, din, nA, go(obs), go(done), go(h0[None])[0], go(mask), go(action), go(old_lp),
                                              go(adv), 0.2, 0.01)
-    lsum = ws.loss_partials.sum(0).cpu().numpy()
+    lsum = lsum_d.cpu().numpy() if fused_out else ws.loss_partials.sum(0).cpu().numpy()
     assert_close(lsum, np.array([la, ent]), 1e-5, "actor loss / entropy", scale=1.0)
     assert_close(ga.cpu().numpy(), g, 1e-4, "recurrent actor gradient")  # north_star: PPO gradients 1e-4
-    for name in ("Wpre", "Wi", "Wh", "bhn", "Whead"):
+    for name in ("Wpre", "Wi", "Wh", "bhn", "Wpost", "bpost", "Whead", "bhead"):
         o, s = actor.off[name]
         n = int(np.prod(s))
         assert_close(ga.cpu().numpy()[o : o + n], g[o : o + n], 1e-4, f"actor grad {name}")
     # ---- critic
     fc_d = d(fc)
-    critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True)
+    critic.forward_sequence(fc_d, ws, obs_d, 1, done_d, h0_d, False, idx_d, T, Rm, E, A, training=True, stop_after_scan=fused_out)
     ov_d, tg_d = d(old_v), d(tgt)
-    check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, 1, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, gscale, ptr(ws.dy),
-                                         ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
     gc = torch.zeros(critic.num_params, device=dev)
-    critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False, grad_scale=gscale)
+    vsum_d = torch.zeros(1, device=dev)
+    if fused_out:
+        assert critic.fused_output(fc_d, ws, idx_d, T, Rm, E, A, 1, False, None, None, ov_d, tg_d, None, 0.2, 0.5, slabs, gc, vsum_d,
+                                   False, gscale)
+    else:
+        check(lib().mava_seq_critic_loss_f32(T, Rm, E, A, 1, ptr(idx_d), ptr(ws.y), ptr(ov_d), ptr(tg_d), 0.2, 0.5, gscale, ptr(ws.dy),
+                                             ptr(ws.loss_partials), ws.loss_partials.shape[0], stream_ptr()), "critic loss")
+    critic.backward_sequence(fc_d, ws, obs_d, 1, done_d, idx_d, T, Rm, E, A, slabs, gc, accumulate=False, grad_scale=gscale,
+                             from_scan=fused_out)
     torch.cuda.synchronize()
     tot, vl, g = ro.rec_critic_loss_grad(fc, din, go(obs), go(done), go(h0[None])[0], go(old_v), go(tgt), 0.2, 0.5)
-    assert_close(ws.loss_partials.sum(0).cpu().numpy()[:1], np.array([vl]), 1e-5, "value loss", scale=1.0)
+    vsum = vsum_d.cpu().numpy() if fused_out else ws.loss_partials.sum(0).cpu().numpy()[:1]
+    assert_close(vsum, np.array([vl]), 1e-5, "value loss", scale=1.0)
     assert_close(gc.cpu().numpy(), g, 1e-4, "recurrent critic gradient")
 
 

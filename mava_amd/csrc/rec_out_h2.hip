@@ -28,6 +28,21 @@ namespace {
 
 using namespace h2;
 
+#ifdef MAVA_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                                  \
+    st_prev = st_now;                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 struct OutTask {
   int T, Rm, E, A, no, agg;
   const int32_t* idx;
@@ -43,6 +58,7 @@ struct OutTask {
   float* dh;                // T32 (T*Rm x 128): d loss / d hs, times grad_scale
   float* slab;              // (gridDim.x, slab_stride)
   long slab_stride;
+  unsigned long long* stamps;  // diagnostic builds (-DMAVA_STAMPS): per-phase cycle sums of block 0, wave 0
 };
 
 constexpr int XPL = 128 * 64;       // bytes per staged plane
@@ -160,13 +176,16 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
   float ab2[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) ab2[q] = 0.0f;
-  float ab3 = 0.0f, loss_a = 0.0f, loss_b = 0.0f;
+  float ab3[NO / 8], loss_a = 0.0f, loss_b = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NO / 8; ++k) ab3[k] = 0.0f;
 
   // ---------------------------------------------------------------- lane mappings
-  constexpr int NP = NO / 8;          // (row, output) pairs per lane
-  constexpr int GR = 64 / NO;         // rows per wave and pair index
-  const int lo = lane & (NO - 1);
-  auto loss_row = [&](int q) -> int { return 8 * w + q * GR + lane / NO; };
+  // loss: eight lanes per row (all 32 rows of the tile in one pass), lane l8 of a row owns outputs l8, l8 + 8, ...
+  constexpr int NP = 1;
+  constexpr int OPL = NO / 8;
+  const int l8 = lane & 7;
+  auto loss_row = [&](int) -> int { return 8 * w + (lane >> 3); };
   const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, g1 = (lane >> 4) & 1;
   const int trI = (8 * h + tq) * IMG_ROW + 2 * (16 * g1 + 4 * tp);
   const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
@@ -185,15 +204,6 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
     f.lo = __builtin_bit_cast(half8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
     return f;
   };
-  // external trajectory row of tile row `row` of tile `it`
-  auto ext_row = [&](long it, int row) -> long {
-    const long q = it * 32 + row;
-    const int t = (int)(q / tk.Rm), m = (int)(q - (long)t * tk.Rm);
-    const int e_local = m / tk.A, a = m - e_local * tk.A;
-    const int env = tk.idx ? tk.idx[e_local] : e_local;
-    return ((long)t * tk.E + env) * tk.A + a;
-  };
-
   float4 raw[4];
   int soff[4];
 #pragma unroll
@@ -203,6 +213,45 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
   const long ntiles = R / 32;
   const long G = gridDim.x;
   long it = blockIdx.x;
+  long n_er[NP];
+  int n_act[NP];
+  float n_f0[NP], n_f1[NP];
+  uint32_t n_m[OPL];
+  // two-deep pipeline: the env ids (idx) of a tile are loaded two tiles ahead, the values behind them one tile ahead -
+  // neither address waits for memory
+  uint32_t p_t[NP], p_a[NP], p_env[NP];
+  auto load_env = [&](long itx) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const uint32_t qq = (uint32_t)itx * 32u + (uint32_t)loss_row(q);
+      const uint32_t t = qq / (uint32_t)tk.Rm, m = qq - t * (uint32_t)tk.Rm;
+      const uint32_t e_local = m / (uint32_t)tk.A;
+      p_t[q] = t;
+      p_a[q] = m - e_local * (uint32_t)tk.A;
+      p_env[q] = tk.idx ? (uint32_t)tk.idx[e_local] : e_local;
+    }
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      n_er[q] = ((long)p_t[q] * tk.E + p_env[q]) * tk.A + p_a[q];
+      n_act[q] = 0;
+      n_f0[q] = n_f1[q] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < OPL; ++k) n_m[k] = 1u;
+      if (ACTOR) {
+        n_act[q] = tk.action[n_er[q]];
+        n_f0[q] = tk.f0[n_er[q]];
+        n_f1[q] = tk.f1[n_er[q]];
+#pragma unroll
+        for (int k = 0; k < OPL; ++k)
+          if (tk.mask != nullptr && l8 + 8 * k < no) n_m[k] = tk.mask[n_er[q] * no + l8 + 8 * k];
+      }
+    }
+  };
+  load_env(it < ntiles ? it : 0);
+  load_rows();
+  load_env(it + G < ntiles ? it + G : (ntiles - 1));
   __syncthreads();
   const float adv_mean = ACTOR ? misc[0] : 0.0f, adv_rstd = ACTOR ? misc[1] : 0.0f;
   if (it < ntiles) {
@@ -218,30 +267,25 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
   }
   __syncthreads();
   int cur = 0;
+  STAMP_DECL
   for (; it < ntiles; it += G) {
+    STAMP(7);
     const u8* const rb = STG + cur * XBUF;
     u8* const wbuf = STG + (cur ^ 1) * XBUF;
     const long itnn = it + 2 * G;
     const long it_issue = itnn < ntiles ? itnn : (ntiles - 1);
-    // loss inputs of this lane's (row, output) pairs: requested now, used after the first barrier
+    // loss inputs of this lane's (row, output) pairs: they sit behind a dependent index load, so they are requested a
+    // whole tile ahead (n_*: the next tile's, loaded below) and rotate in here
     long er[NP];
     int r_act[NP];
     float r_f0[NP], r_f1[NP];
-    uint32_t r_m[NP];
+    uint32_t r_m[OPL];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      er[q] = ext_row(it, loss_row(q));
-      r_m[q] = 1u;
-      if (ACTOR) {
-        r_act[q] = tk.action[er[q]];
-        r_f0[q] = tk.f0[er[q]];
-        r_f1[q] = tk.f1[er[q]];
-        if (tk.mask != nullptr && lo < no) r_m[q] = tk.mask[er[q] * no + lo];
-      } else {
-        r_act[q] = 0;
-        r_f0[q] = r_f1[q] = 0.0f;
-      }
-    }
+    for (int q = 0; q < NP; ++q) { er[q] = n_er[q]; r_act[q] = n_act[q]; r_f0[q] = n_f0[q]; r_f1[q] = n_f1[q]; }
+#pragma unroll
+    for (int k = 0; k < OPL; ++k) r_m[k] = n_m[k];
+    load_rows();                                                   // tile it + G (its env ids arrived a tile ago)
+    load_env(it + 2 * G < ntiles ? it + 2 * G : (ntiles - 1));     // tile it + 2G
 
     // ---------------------------------------------------------------- P1: post = relu(Wpost^T hs^T + b), head partials
     f32x16 acc;
@@ -284,69 +328,97 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
         }
       }
     }
+    STAMP(0);
     __syncthreads();  // B: partial logits and the post image complete
+    STAMP(1);
 
     // ---------------------------------------------------------------- P3: loss, d loss / d outputs (grad_scale units)
     {
       const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
+      const int row = loss_row(0);
+      float y[OPL], dyo[OPL];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const int row = loss_row(q);
-        const float* yp = YP + row * (NO + 1) + lo;
-        const float y = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[lo];
-        float dyo = 0.0f;
-        if (ACTOR) {
-          const bool legal = (lo < no) && (r_m[q] != 0u);
-          const float z = legal ? y : -FLT_MAX;
-          auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
-          auto add_op = [](float a, float b) { return a + b; };
-          const float mx = group_allreduce<NO>(z, fmax_op);
-          const float se = group_allreduce<NO>(expf(z - mx), add_op);
-          const float logp = z - (mx + logf(se));
-          const float pr = expf(logp);
-          const float ent = group_allreduce<NO>((pr > 0.0f) ? -(pr * logp) : 0.0f, add_op);
-          const int act = r_act[q];
-          const float lp = group_allreduce<NO>((lo == act) ? logp : 0.0f, add_op);
-          const float gae = (r_f1[q] - adv_mean) * adv_rstd;
-          const float ratio = expf(lp - r_f0[q]);
-          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
-          const float l1 = ratio * gae, l2 = rc * gae;
-          const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
-          const float g1w = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-          const float g2w = inside ? (1.0f - g1w) : 0.0f;
-          const float dlp = -(g1w + g2w) * gae * ratio * gsc;
-          const float ec = tk.coef * gsc;
-          const float oh = (lo == act) ? 1.0f : 0.0f;
-          const float pl2 = (pr > 0.0f) ? logp : 0.0f;
-          dyo = dlp * (oh - pr) + ec * pr * (pl2 + ent);
-          if (z == -FLT_MAX) dyo = 0.0f;
-          if (lo == 0) {
-            loss_a += -fminf(l1, l2) * invR;
-            loss_b += ent * invR;
-          }
-        } else if (lo == 0) {
-          // one value per row; with agg > 1 the row is shared by its agg agents: their loss gradients add up
-          for (int a2 = 0; a2 < na; ++a2) {
-            const long ea = er[q] * na + a2;
-            const float ov = tk.f0[ea], tg = tk.f1[ea];
-            const float diff = y - ov;
-            const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
-            const float e1 = y - tg, e2 = vclip - tg;
-            const float l1 = e1 * e1, l2 = e2 * e2;
-            const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
-            const float g1w = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-            const float g2w = inside ? (1.0f - g1w) : 0.0f;
-            dyo += tk.coef * (g1w * e1 + g2w * e2) * gsc;
-            loss_a += 0.5f * fmaxf(l1, l2) * invR;
-          }
+      for (int k = 0; k < OPL; ++k) {
+        const int o = l8 + 8 * k;
+        const float* yp = YP + row * (NO + 1) + o;
+        y[k] = (((yp[0] + yp[32 * (NO + 1)]) + yp[2 * 32 * (NO + 1)]) + yp[3 * 32 * (NO + 1)]) + B3s[o];
+        dyo[k] = 0.0f;
+      }
+      if (ACTOR) {
+        auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
+        auto add_op = [](float a, float b) { return a + b; };
+        // masked Categorical over the row's outputs (networks.py:116-124, distributions.py:146-165)
+        float z[OPL], logp[OPL], pr[OPL];
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) {
+          const bool legal = (l8 + 8 * k < no) && (r_m[k] != 0u);
+          z[k] = legal ? y[k] : -FLT_MAX;
+          mx = fmaxf(mx, z[k]);
         }
+        mx = group_allreduce<8>(mx, fmax_op);
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) se += expf(z[k] - mx);
+        se = group_allreduce<8>(se, add_op);
+        const float lse = mx + logf(se);
+        const int act = r_act[0];
+        float ent = 0.0f, lp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) {
+          logp[k] = z[k] - lse;
+          pr[k] = expf(logp[k]);
+          ent += (pr[k] > 0.0f) ? -(pr[k] * logp[k]) : 0.0f;
+          lp += (l8 + 8 * k == act) ? logp[k] : 0.0f;
+        }
+        ent = group_allreduce<8>(ent, add_op);
+        lp = group_allreduce<8>(lp, add_op);
+        const float gae = (r_f1[0] - adv_mean) * adv_rstd;
+        const float ratio = expf(lp - r_f0[0]);
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+        const float l1 = ratio * gae, l2 = rc * gae;
+        const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
+        const float g1w = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+        const float g2w = inside ? (1.0f - g1w) : 0.0f;
+        const float dlp = -(g1w + g2w) * gae * ratio * gsc;
+        const float ec = tk.coef * gsc;
+#pragma unroll
+        for (int k = 0; k < OPL; ++k) {
+          const float oh = (l8 + 8 * k == act) ? 1.0f : 0.0f;
+          const float pl2 = (pr[k] > 0.0f) ? logp[k] : 0.0f;
+          dyo[k] = dlp * (oh - pr[k]) + ec * pr[k] * (pl2 + ent);
+          if (z[k] == -FLT_MAX) dyo[k] = 0.0f;
+        }
+        if (l8 == 0) {
+          loss_a += -fminf(l1, l2) * invR;
+          loss_b += ent * invR;
+        }
+      } else if (l8 == 0) {
+        // one value per row; with agg > 1 the row is shared by its agg agents: their loss gradients add up
+        for (int a2 = 0; a2 < na; ++a2) {
+          const long ea = er[0] * na + a2;
+          const float ov = tk.f0[ea], tg = tk.f1[ea];
+          const float diff = y[0] - ov;
+          const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+          const float e1 = y[0] - tg, e2 = vclip - tg;
+          const float l1 = e1 * e1, l2 = e2 * e2;
+          const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+          const float g1w = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+          const float g2w = inside ? (1.0f - g1w) : 0.0f;
+          dyo[0] += tk.coef * (g1w * e1 + g2w * e2) * gsc;
+          loss_a += 0.5f * fmaxf(l1, l2) * invR;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < OPL; ++k) {
         _Float16 da, db;
-        split1(dyo, da, db);
-        *reinterpret_cast<_Float16*>(DYI + row * DY_ROW + 2 * lo) = da;
-        *reinterpret_cast<_Float16*>(DYI + DY_PLANE + row * DY_ROW + 2 * lo) = db;
-        ab3 += dyo;
+        split1(dyo[k], da, db);
+        *reinterpret_cast<_Float16*>(DYI + row * DY_ROW + 2 * (l8 + 8 * k)) = da;
+        *reinterpret_cast<_Float16*>(DYI + DY_PLANE + row * DY_ROW + 2 * (l8 + 8 * k)) = db;
+        ab3[k] += dyo[k];
       }
     }
+    STAMP(2);
     __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
 
     // ---------------------------------------------------------------- P4: dWhead, dpost
@@ -370,18 +442,27 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
       half4 ph[4], pl[4];
       write_image(DPOSTI, r, 32 * w + 4 * h, dz, ph, pl);
     }
+    STAMP(3);
     __syncthreads();  // C: dpost image complete
+    STAMP(4);
 
     // ---------------------------------------------------------------- P5: dh = Wpost dpost^T (stored), dWpost; next tile staged
     {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      // two independent chains share the phase: dh (8 steps on one accumulator) and dWpost (2 row steps x 4 feature tiles);
+      // step s of the first is issued next to product s of the second
       Frag bn = read_row_frag(DPOSTI, IMG_PLANE, r * IMG_ROW + 16 * h);
+      Frag gb = read_tr_frag(DPOSTI + trI + 2 * (32 * w), IMG_PLANE, IMG_ROW);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const Frag b = bn;
         if (s + 1 < 8) bn = read_row_frag(DPOSTI, IMG_PLANE, r * IMG_ROW + 16 * h + 32 * (s + 1));
+        const int s2 = s >> 2, t = s & 3;
+        const Frag ga = rows_frag(rb, 32 * t + r, 2 * s2 + h);
         acc = mfma3(wfb[s], b, acc);
+        gWp[t] = mfma3(ga, gb, gWp[t]);
+        if (s == 3) gb = read_tr_frag(DPOSTI + trI + 16 * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
         if (s & 1) {  // half a slot of the next tile's commit per two steps, and the loads of the tile after it
           const int k = s >> 1;
           stage4(wbuf, soff[k], raw[k]);
@@ -392,21 +473,17 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
       float* const dho = tk.dh + ((it * MLP_H + 32 * w + 4 * h) * 32 + r);
 #pragma unroll
       for (int q = 0; q < 16; ++q) dho[((q & 3) + 8 * (q >> 2)) * 32] = acc[q];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const Frag b = read_tr_frag(DPOSTI + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const Frag a = rows_frag(rb, 32 * t + r, 2 * s + h);
-          gWp[t] = mfma3(a, b, gWp[t]);
-          if (t & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
     }
+    STAMP(5);
     __syncthreads();  // D: images and the staging buffers change hands
+    STAMP(6);
     cur ^= 1;
   }
 
+#ifdef MAVA_STAMPS
+  if (tk.stamps != nullptr && blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) tk.stamps[i] = st_acc[i];
+#endif
   // ---------------------------------------------------------------- epilogue: slabs (true units)
   float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
   const float inv = 1.0f / tk.grad_scale;
@@ -430,11 +507,14 @@ __global__ __launch_bounds__(256, 1) void rec_out_h2_kernel(OutTask tk) {
   }
   float* red = misc + 2;
   {
-    float v = ab3;
-#pragma unroll
-    for (int m = NO; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
     __syncthreads();
-    if (lane < NO) red[w * NO + lane] = v;
+#pragma unroll
+    for (int k = 0; k < NO / 8; ++k) {  // lanes with the same l8 hold output l8 + 8k of different rows
+      float v = ab3[k];
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (lane < 8) red[w * NO + lane + 8 * k] = v;
+    }
     for (int o = 32; o > 0; o >>= 1) {
       loss_a += __shfl_down(loss_a, o, 64);
       loss_b += __shfl_down(loss_b, o, 64);
@@ -465,6 +545,13 @@ int launch_out(const OutTask& tk, int n_slab, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_out_stamps = nullptr;
+// Diagnostic hook (not part of include/mava_hip.h): device buffer of 8 u64 for -DMAVA_STAMPS builds.
+extern "C" int mava_debug_set_out_stamps(unsigned long long* p) {
+  g_out_stamps = p;
+  return MAVA_OK;
+}
+
 // Returns 1 when the shape is not instantiated (the caller runs the layer-wise kernels).
 extern "C" int mava_rec_out_f32(int T, int Rm, int E, int A, int n_out, int agents_per_row, const int32_t* idx, const float* hs,
                                 const float* params_post_head, const uint8_t* mask, const int32_t* action, const float* f0,
@@ -481,6 +568,7 @@ extern "C" int mava_rec_out_f32(int T, int Rm, int E, int A, int n_out, int agen
   tk.params = params_post_head; tk.mask = mask; tk.action = action; tk.f0 = f0; tk.f1 = f1; tk.stats = adv_stats;
   tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = coef; tk.grad_scale = grad_scale; tk.dh = dh; tk.slab = slab;
   tk.slab_stride = slab_stride;
+  tk.stamps = g_out_stamps;
   if (!is_actor) return launch_out<8, false>(tk, n_slab, s);
   if (n_out <= 8) return launch_out<8, true>(tk, n_slab, s);
   return launch_out<16, true>(tk, n_slab, s);

@@ -404,11 +404,30 @@ __global__ __launch_bounds__(256) void rec_gather_t32_kernel(DenseTask tk, int K
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ntiles = tk.rows / 32;
   for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+    // all eight row addresses of this wave first (each sits behind an index load), then all row loads: no round trip per row
+    const float* xrow[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = 8 * w + rr;
-      const float* xrow = tk.x + gather_row(tk, it * 32 + r) * tk.x_ld;
-      for (int c = lane; c < KP; c += 64) xs[r * ld + c] = c < K ? xrow[c] : 0.0f;
+    for (int rr = 0; rr < 8; ++rr) xrow[rr] = tk.x + gather_row(tk, it * 32 + 8 * w + rr) * tk.x_ld;
+    if (KP <= 256) {
+      float v[8][4];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = lane + 64 * cc;
+          v[rr][cc] = xrow[rr][c < K ? c : 0];
+        }
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = lane + 64 * cc;
+          if (c < KP) xs[(8 * w + rr) * ld + c] = c < K ? v[rr][cc] : 0.0f;
+        }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        for (int c = lane; c < KP; c += 64) xs[(8 * w + rr) * ld + c] = c < K ? xrow[rr][c] : 0.0f;
     }
     __syncthreads();
     float* out = tk.y + (long)it * KP * 32;

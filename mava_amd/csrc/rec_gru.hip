@@ -23,11 +23,12 @@ namespace {
 constexpr int LDT = 33;
 constexpr int G3 = 3 * MLP_H;
 
-// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the scan's
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each; __builtin_amdgcn_rcpf:
+// __frcp_rn expands to the ten-instruction correctly rounded division): the scan's
 // elementwise phase runs with the MFMA pipe idle (one wave per SIMD), and libm's expf / tanhf / IEEE division cost
 // ~8 K of the ~27 K cycles a time step took.  tanh(x) = 1 - 2 / (exp(2x) + 1) saturates correctly at both ends.
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 __global__ __launch_bounds__(256, 1) void gru_scan_fwd_kernel(ScanTask tk) {
   __shared__ float HT[MLP_H * LDT];
@@ -556,6 +557,7 @@ extern "C" int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t*
   MAVA_ARG_CHECK(T >= 1 && Rm >= 32 && Rm % 32 == 0 && E >= 1 && A >= 1 && Rm % A == 0, 0,
                  "mava_gru_scan_fwd_f32: T=%d Rm=%d E=%d A=%d (Rm must be a multiple of 32 and of A)", T, Rm, E, A);
   MAVA_ARG_CHECK(done && h0 && wh && bhn && gi && hs, 1, "mava_gru_scan_fwd_f32: null pointer argument");
+  MAVA_ARG_CHECK((hprev == nullptr) == (saved == nullptr), 2, "mava_gru_scan_fwd_f32: hprev and saved come together (training) or not at all");
   ScanTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.h0 = h0; tk.h0_t32 = h0_t32;
   tk.wh = wh; tk.bhn = bhn; tk.gi = gi; tk.hs = hs; tk.hprev = hprev; tk.saved = saved;

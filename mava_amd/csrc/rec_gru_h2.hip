@@ -32,8 +32,24 @@ constexpr int GIMG = 2 * GPLANE;
 
 #define OFFW(r) ((((r) & 3) + 8 * ((r) >> 2)) * 32)
 
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+#ifdef MAVA_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                                  \
+    st_prev = st_now;                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+__device__ unsigned long long* g_scan_stamps = nullptr;
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 // 16 values of a lane (register q <-> feature col0 + (q & 3) + 8 (q >> 2), row r) -> split -> image row r
 template <int ROWB, int PLANE>
@@ -52,6 +68,22 @@ __device__ __forceinline__ void put16(u8* img, int r, int col0, const float (&v)
     *reinterpret_cast<half4*>(p) = ph;
     *reinterpret_cast<half4*>(p + PLANE) = pl;
   }
+}
+
+// The reset flags of one sequence, 32 time steps per word.  A flag read inside the time loop sits behind an index load and
+// (memory operations retire in order) behind every store of the step before it: it stalled each step for thousands of
+// cycles.  Loaded as a chunk it costs one round trip per 32 steps.  base = address of the flag of step 0, stride = E * A.
+__device__ __forceinline__ uint32_t done_chunk(const uint8_t* base, long stride, int t0, int T) {
+  uint8_t f[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int t = t0 + i;
+    f[i] = base[(long)(t < T ? t : (T - 1)) * stride];
+  }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) bits |= (f[i] != 0 && t0 + i < T) ? (1u << i) : 0u;
+  return bits;
 }
 
 __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
@@ -81,15 +113,19 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
   for (int r = 0; r < 16; ++r) bn[r] = tk.bhn[fb + (r & 3) + 8 * (r >> 2)];
 
   // masked hidden state entering the current step: this lane's 16 (feature, row) elements
+  const long row0 = ext_row(tk, 0, m);                 // (the env id behind it is loaded once)
+  const uint8_t* const done0 = tk.done + row0;
+  const long dstride = (long)tk.E * tk.A;
+  uint32_t dbits = done_chunk(done0, dstride, 0, tk.T);  // flags of steps 32c .. 32c + 31 of the current chunk
   float hp[16];
   {
-    const bool rs = tk.done[ext_row(tk, 0, m)] != 0;
+    const bool rs = (dbits & 1u) != 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2);
       float v;
       if (tk.h0_t32) v = tk.h0[((long)mt * MLP_H + f) * 32 + j];
-      else v = tk.h0[ext_row(tk, 0, m) * MLP_H + f];
+      else v = tk.h0[row0 * MLP_H + f];
       hp[r] = rs ? 0.0f : v;
     }
     put16<HROW, HPLANE>(IMG, j, fb, hp);
@@ -107,7 +143,9 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
     }
   };
   load_gi(0);
+  STAMP_DECL
   for (int t = 0; t < tk.T; ++t) {
+    STAMP(0);
     const long tile = (long)t * tiles_per_t + mt;
     const u8* const img = IMG + (t & 1) * HIMG;
     u8* const img_next = IMG + ((t + 1) & 1) * HIMG;
@@ -115,9 +153,12 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
     float gn[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ar[r] = gr[r]; az[r] = gz[r]; gn[r] = gin[r]; an[r] = bn[r]; }
-    const bool rs_next = (t + 1 < tk.T) ? (tk.done[ext_row(tk, t + 1, m)] != 0) : false;
+    if (((t + 1) & 31) == 0 && t + 1 < tk.T) dbits = done_chunk(done0, dstride, t + 1, tk.T);
+    const bool rs_next = (t + 1 < tk.T) ? (((dbits >> ((t + 1) & 31)) & 1u) != 0) : false;
     if (t + 1 < tk.T) load_gi(t + 1);  // in flight during the step
+    STAMP(1);
     __syncthreads();  // image of h entering step t complete (and every wave is past its reads of the other buffer)
+    STAMP(2);
     {
       const int ro = j * HROW + 16 * h;  // features 8h .. 8h + 7 of row j; batch b adds 32 bytes
       Frag hf[2];
@@ -131,29 +172,45 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(3);
     float hn[16];
     float* const hs_o = tk.hs + tile * (MLP_H * 32) + lane_off;
-    float* const hp_o = tk.hprev ? tk.hprev + tile * (MLP_H * 32) + lane_off : nullptr;
-    float* const sv = tk.saved ? tk.saved + tile * (4 * MLP_H) * 32 + lane_off : nullptr;
+    if (tk.saved != nullptr && tk.hprev != nullptr) {  // training: one uniform branch, straight-line stores
+      float* const hp_o = tk.hprev + tile * (MLP_H * 32) + lane_off;
+      float* const sv = tk.saved + tile * (4 * MLP_H) * 32 + lane_off;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float rr = sigmoidf_(ar[r]);
-      const float zz = sigmoidf_(az[r]);
-      const float nn = tanhf_(gn[r] + rr * an[r]);
-      hn[r] = (1.0f - zz) * nn + zz * hp[r];
-      hs_o[OFFW(r)] = hn[r];
-      if (hp_o != nullptr) hp_o[OFFW(r)] = hp[r];
-      if (sv != nullptr) {
+      for (int r = 0; r < 16; ++r) {
+        const float rr = sigmoidf_(ar[r]);
+        const float zz = sigmoidf_(az[r]);
+        const float nn = tanhf_(gn[r] + rr * an[r]);
+        hn[r] = (1.0f - zz) * nn + zz * hp[r];
+        hs_o[OFFW(r)] = hn[r];
+        hp_o[OFFW(r)] = hp[r];
         sv[OFFW(r)] = rr;
         sv[MLP_H * 32 + OFFW(r)] = zz;
         sv[2 * MLP_H * 32 + OFFW(r)] = nn;
         sv[3 * MLP_H * 32 + OFFW(r)] = an[r];
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rr = sigmoidf_(ar[r]);
+        const float zz = sigmoidf_(az[r]);
+        const float nn = tanhf_(gn[r] + rr * an[r]);
+        hn[r] = (1.0f - zz) * nn + zz * hp[r];
+        hs_o[OFFW(r)] = hn[r];
+      }
     }
+    STAMP(4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hp[r] = rs_next ? 0.0f : hn[r];
     put16<HROW, HPLANE>(img_next, j, fb, hp);
+    STAMP(5);
   }
+#ifdef MAVA_STAMPS
+  if (g_scan_stamps != nullptr && blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) g_scan_stamps[i] = st_acc[i];
+#endif
 }
 
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
@@ -199,10 +256,14 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
     }
   };
   load_step(tk.T - 1);
+  const uint8_t* const done0 = tk.done + ext_row(tk, 0, m);
+  const long dstride = (long)tk.E * tk.A;
+  uint32_t dbits = done_chunk(done0, dstride, (tk.T - 1) & ~31, tk.T);
   for (int t = tk.T - 1; t >= 0; --t) {
     const long tile = (long)t * tiles_per_t + mt;
     u8* const img = DIMG + (t & 1) * GIMG;
-    const bool rs = tk.done[ext_row(tk, t, m)] != 0;
+    if ((t & 31) == 31 && t != tk.T - 1) dbits = done_chunk(done0, dstride, t & ~31, tk.T);
+    const bool rs = ((dbits >> (t & 31)) & 1u) != 0;
     float dhp[16], g_r[16], g_z[16], g_n[16];
     float* const gi_o = tk.dgi + tile * G3 * 32 + lane_off;
     float* const gh_o = tk.dgh + tile * G3 * 32 + lane_off;
@@ -254,6 +315,12 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
 }
 
 }  // namespace
+
+#ifdef MAVA_STAMPS
+extern "C" int mava_debug_set_scan_stamps(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stamps), &p, sizeof(p));
+}
+#endif
 
 int mava_gru_scan_fwd_h2_launch(const ScanTask& tk, hipStream_t s) {
   hipLaunchKernelGGL(gru_scan_fwd_h2_kernel, dim3(tk.Rm / 32), dim3(256), 0, s, tk);

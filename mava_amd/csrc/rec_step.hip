@@ -22,8 +22,8 @@ namespace {
 constexpr int LDT = 33;
 constexpr int G3 = 3 * MLP_H;
 
-__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 // acc[g] += W[:, cols_g]^T . B^T over nb batches of 16 inputs.  W(k, c) = wbase[k * ldw + c]; lane (i = j, half h)
 // supplies W(k + h, col_g + j).  B is an LDS tile: element (k, row j) at bt[k * bk + j * bj] (a [k][row] exchange tile:

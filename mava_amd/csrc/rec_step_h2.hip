@@ -27,8 +27,8 @@ constexpr int IROW = h2::IMG_ROW;     // 272: [row][128 f16 + 16]
 constexpr int IPLANE = 32 * IROW;
 constexpr int IIMG = 2 * IPLANE;      // 17408
 
-__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 // fragment f of a packed matrix: [f][plane hi, lo][lane][16 bytes]
 __device__ __forceinline__ Frag load_frag(const u8* base, int f, int lane) {

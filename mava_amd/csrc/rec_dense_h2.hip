@@ -64,7 +64,10 @@ __device__ __forceinline__ Frag rows_frag(const u8* plane_hi, int plane_bytes, i
 
 // Y = act(X W + b) [gated] for T32 X (x_ld features per tile, the first K used).
 // NB = 16-input batches of K, NTW = 32-feature output tiles per wave (tiles w, w+4, w+8).
-template <int NB, int NTW>
+// LEAN (the K = 384 instantiation, whose 192 weight registers leave no slack): no bias registers (the caller passes no
+// bias), staging offsets recomputed instead of held, the gate values of a tile requested at its start instead of a tile
+// ahead - the 48 registers this frees were spilled and reloaded every tile otherwise (and a reload drains the prefetch).
+template <int NB, int NTW, bool LEAN = false>
 __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
   extern __shared__ __attribute__((aligned(16))) u8 lds[];
   constexpr int XF = 16 * NB;          // staged features
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
   // features past K are never staged: they must read as zeros (their weights are zero, 0 * garbage may be NaN)
   for (int i = tid; i < 2 * BUF / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float breg[NTW][16];
+  float breg[LEAN ? 1 : NTW][16];
 #pragma unroll
-  for (int tw = 0; tw < NTW; ++tw)
+  for (int tw = 0; tw < (LEAN ? 0 : NTW); ++tw)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = 32 * (w + 4 * tw) + 4 * h + (r & 3) + 8 * (r >> 2);
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
   };
 
   float4 raw[XS];
-  int soff[XS];
+  int soff[LEAN ? 1 : XS];
 #pragma unroll
-  for (int k = 0; k < XS; ++k) soff[k] = stage_off(tid + 256 * k);
+  for (int k = 0; k < (LEAN ? 0 : XS); ++k) soff[k] = stage_off(tid + 256 * k);
   auto issue = [&](int it, int k) {
     const float4* xs = reinterpret_cast<const float4*>(tk.x + (long)it * tk.x_ld * 32);
     const int q = tid + 256 * k;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
     float4 v = raw[k];
     v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
     // an odd NB stages 128 NB float4: the upper half of the block has no feature row in the last slot
-    if (!(NB & 1) || k < XS - 1 || tid < 128) stage4(buf, XPL, soff[k], v);
+    if (!(NB & 1) || k < XS - 1 || tid < 128) stage4(buf, XPL, LEAN ? stage_off(tid + 256 * k) : soff[k], v);
   };
   // Output tile: activation, optional relu-mask gate, coalesced T32 stores.  A wave whose 32 features all exist takes a
   // straight-line path (wave-uniform scalar branches only): per-element bounds checks and pointer tests cost a tile more
@@ -222,8 +225,10 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
 #pragma unroll
     for (int k = 0; k < XS; ++k) issue(itn < ntiles ? itn : (ntiles - 1), k);
   }
-  float gcur[16], gnext[16];
-  if (pf_gate && it < ntiles) load_gate(it, gnext);
+  float gcur[16], gnext[LEAN ? 1 : 16];
+  if constexpr (!LEAN) {
+    if (pf_gate && it < ntiles) load_gate(it, gnext);
+  }
   __syncthreads();
   int cur = 0;
   for (; it < ntiles; it += G) {
@@ -233,15 +238,19 @@ __global__ __launch_bounds__(256, 1) void rec_dense_h2_kernel(DenseTask tk) {
     const bool has_next = itn < ntiles;
     const int it_issue = itnn < ntiles ? itnn : (ntiles - 1);
     if (pf_gate) {
+      if constexpr (LEAN) {
+        load_gate(it, gcur);  // used a whole tile of matrix work later
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gcur[r] = gnext[r];
-      load_gate(has_next ? itn : it, gnext);
+        for (int r = 0; r < 16; ++r) gcur[r] = gnext[r];
+        load_gate(has_next ? itn : it, gnext);
+      }
     }
     f32x16 acc[NTW];
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tw][r] = breg[tw][r];
+      for (int r = 0; r < 16; ++r) acc[tw][r] = LEAN ? 0.0f : breg[tw][r];
     if (tk.accumulate) {  // K-chunked products (inputs wider than 384): start from the existing output
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
@@ -436,17 +445,17 @@ __global__ __launch_bounds__(256) void rec_gather_t32_kernel(DenseTask tk, int K
   }
 }
 
-template <int NB, int NTW>
+template <int NB, int NTW, bool LEAN = false>
 int launch_dense_h2(const DenseTask& tk, hipStream_t s) {
   constexpr int lb = 2 * 2 * 16 * NB * 64;  // two buffers of hi + lo planes
   static bool attr_set = false;
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_h2_kernel<NB, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_dense_h2_kernel<NB, NTW, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     attr_set = true;
   }
   int blocks = tk.rows / 32;
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL((rec_dense_h2_kernel<NB, NTW>), dim3(blocks), dim3(256), lb, s, tk);
+  hipLaunchKernelGGL((rec_dense_h2_kernel<NB, NTW, LEAN>), dim3(blocks), dim3(256), lb, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
@@ -476,7 +485,11 @@ int mava_rec_dense_h2_launch(const DenseTask& tk, hipStream_t s) {
 #define DENSE_H2(NBv, NTWv) \
   if (nb <= NBv && ntw == NTWv) return launch_dense_h2<NBv, NTWv>(tk, s)
   DENSE_H2(1, 1); DENSE_H2(2, 1); DENSE_H2(4, 1); DENSE_H2(6, 1); DENSE_H2(8, 1); DENSE_H2(10, 1); DENSE_H2(12, 1);
-  DENSE_H2(18, 1); DENSE_H2(24, 1); DENSE_H2(8, 3);
+  DENSE_H2(18, 1); DENSE_H2(8, 3);
+  if (nb <= 24 && ntw == 1) {
+    if (tk.bias != nullptr) return 1;  // (the lean K = 384 form carries no bias registers: the exact-f32 kernel takes it)
+    return launch_dense_h2<24, 1, true>(tk, s);
+  }
 #undef DENSE_H2
   return 1;
 }

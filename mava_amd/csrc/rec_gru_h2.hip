@@ -11,6 +11,11 @@
 //    features of its row) is one ds_read_b128 per plane;
 //  * the image is double-buffered, so a step has one block barrier instead of two; the f32 hidden state a lane needs for
 //    h' = (1-z) n + z h is the one it produced itself and stays in its registers.
+// (Measured and rejected: the products the other way round - lane = feature, the 16 accumulator registers = 16 rows, so
+// that every T32 access is 16 bytes and a step needs 36 / 48 memory instructions instead of 144 / 192.  Each such
+// instruction touches 32 separate 128-byte lines for 32 bytes each; the texture path handles lines, not bytes, and the
+// forward scan went from 0.52 to 0.69 ms (critic-sized launch).  The four-byte accesses below cover two FULL lines per
+// instruction.)
 // Backward: the gate gradients must sit in f16's range - the caller runs the backward chain in units of a power of two
 // near the row count (mava_seq_*_loss_f32 grad_scale).
 #include "h2_core.h"

@@ -22,6 +22,22 @@ using h2::half4;
 using h2::half8;
 using h2::u8;
 
+#ifdef MAVA_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_prev;                                  \
+    st_prev = st_now;                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+__device__ unsigned long long* g_step_stamps = nullptr;
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 constexpr int G3 = 3 * MLP_H;
 constexpr int IROW = h2::IMG_ROW;     // 272: [row][128 f16 + 16]
 constexpr int IPLANE = 32 * IROW;
@@ -87,6 +103,17 @@ __global__ __launch_bounds__(64) void rec_pack_kernel(const float* __restrict__ 
   }
 }
 
+#ifdef MAVA_STAMPS
+#define STAMP_FLUSH()                                                          \
+  do {                                                                         \
+    STAMP(10);                                                                 \
+    if (g_step_stamps != nullptr && grp == 0 && ACTOR && threadIdx.x == 0)     \
+      for (int i = 0; i < 12; ++i) g_step_stamps[i] = st_acc[i];               \
+  } while (0)
+#else
+#define STAMP_FLUSH()
+#endif
+
 struct NetH2 {
   RecNet n;
   const u8* pack;
@@ -102,9 +129,8 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
   const int din = nt.din, no = nt.no, nb1 = nh.nb1, XROW = nh.xrow, XPLANE = 32 * nh.xrow;
   u8* const RA = lds;                                   // X images, later the E images (RT x abytes)
   u8* const RB = lds + RT * nh.abytes;                  // masked-h images, later the new-h images (RT x IIMG)
-  float* const W3s = reinterpret_cast<float*>(RB + RT * IIMG);
-  float* const YP = W3s + MLP_H * NO;                   // [RT][4][NO][32]
-  float* const BS = YP + RT * 4 * NO * 32;              // biases: bpre | bi (384) | bhn | bpost
+  float* const YP = reinterpret_cast<float*>(RB + RT * IIMG);  // [RT][4][NO][32]
+  float* const BS = YP + RT * 4 * NO * 32;              // biases: bpre | bi (384) | bhn | bpost | bhead (NO)
   const float* const bpre = nt.params + (long)din * MLP_H;
   const float* const bi = bpre + MLP_H + MLP_H * G3;
   const float* const bhn = bi + G3 + MLP_H * G3;
@@ -121,24 +147,35 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
 
   // Weight fragments come from L2 (~1 us away under load) and a batch of a 128-wide layer is only 9 RT matrix
   // instructions: every layer's fragments run through a ring whose first loads are issued a phase early.
+  STAMP_DECL
   constexpr int DP = 6;  // ring depth of the 128-wide layers (pre_torso, post_torso)
   Frag rp[DP];
 #pragma unroll
   for (int d = 0; d < DP; ++d) rp[d] = load_frag(Ppre, w * nb1 + (d < nb1 ? d : nb1 - 1), lane);
-  for (int i = tid; i < MLP_H * NO; i += 256) {
-    const int f = i / NO, o = i - f * NO;
-    W3s[i] = (o < no) ? Whead[f * no + o] : 0.0f;
-  }
-  // biases of all layers -> LDS once (a per-phase global read would sit in front of each phase's first MFMA)
-  for (int i = tid; i < 6 * MLP_H; i += 256) {
+  // ---- every global load of the staging phase is issued first (head fragments, biases, the x rows, the hidden state and its
+  // reset flags), then consumed: one memory round trip for the phase instead of one per consumer
+  // head fragments (A operand of logits^T[o][row] over this wave's 32 features; the B operand is the post_torso
+  // accumulator itself): element e = Whead[32w + 16s + 8(e>>2) + 4h + (e&3)][o = j], scaled into f16's normal range
+  float w3v[2][8];
+#pragma unroll
+  for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = 32 * w + 16 * sgm + 8 * (e >> 2) + 4 * h + (e & 3);
+      w3v[sgm][e] = Whead[f * no + (j < no ? j : 0)];
+    }
+  float bv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = tid + 256 * k;
     const float* src = i < MLP_H ? bpre + i : (i < 4 * MLP_H ? bi + (i - MLP_H) : (i < 5 * MLP_H ? bhn + (i - 4 * MLP_H) : bpost + (i - 5 * MLP_H)));
-    BS[i] = *src;
+    bv[k] = *src;
   }
-  // ---- stage the x tiles (row-major rows -> split image) and the masked hidden state.  Wave w takes rows 8w .. 8w + 7 of
-  // every tile, a lane one column per 64-column chunk: ALL loads of the group are issued before the first is used (a
-  // row-by-row loop pays one memory round trip per row)
-  if (nb1 <= 12) {
-    float xv[RT][8][3];
+  const float bh = bhead[tid < no ? tid : 0];
+  // x tiles: wave w takes rows 8w .. 8w + 7 of every tile, a lane one column per 64-column chunk
+  const bool fast_x = nb1 <= 12;
+  float xv[RT][8][3];
+  if (fast_x) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -152,6 +189,37 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
           xv[rt][q][cc] = xrow[c < din ? c : 0];
         }
       }
+  }
+  // masked hidden state entering the step.  The f32 values are NOT kept across the GRU product (48 registers that were
+  // spilled and came back one scratch round trip at a time): they are read again before the gate arithmetic.
+  uint32_t rs_bits = 0;
+  auto load_hp = [&](int rt, float (&v)[16]) {
+    const int it = (it0 + rt < ntiles) ? (it0 + rt) : (ntiles - 1);
+    const float* hin = nt.h_in + ((long)it * MLP_H + fb) * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = hin[((r & 3) + 8 * (r >> 2)) * 32];
+  };
+  float hv[RT][16];
+  uint8_t dn[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int it = (it0 + rt < ntiles) ? (it0 + rt) : (ntiles - 1);
+    dn[rt] = nt.done[(long)(it * 32 + j) * nt.done_stride];  // networks.py:253-257
+    load_hp(rt, hv[rt]);
+  }
+
+  // ---- consume
+  Frag W3h[2];
+#pragma unroll
+  for (int sgm = 0; sgm < 2; ++sgm) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w3v[sgm][e] = (j < no) ? w3v[sgm][e] * h2::W3_SCALE : 0.0f;
+    W3h[sgm] = h2::split8(w3v[sgm]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) BS[tid + 256 * k] = bv[k];
+  if (tid < NO) BS[6 * MLP_H + tid] = tid < no ? bh : 0.0f;
+  if (fast_x) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -183,20 +251,17 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
       }
     }
   }
-  float hp[RT][16];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int it = (it0 + rt < ntiles) ? (it0 + rt) : (ntiles - 1);
-    const bool rs = nt.done[(long)(it * 32 + j) * nt.done_stride] != 0;  // networks.py:253-257
-    const float* hin = nt.h_in + ((long)it * MLP_H + fb) * 32 + j;
+    const bool rs = dn[rt] != 0;
+    rs_bits |= rs ? (1u << rt) : 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = hin[((r & 3) + 8 * (r >> 2)) * 32];
-      hp[rt][r] = rs ? 0.0f : v;
-    }
-    put16<IROW, IPLANE>(RB + rt * IIMG, j, fb, hp[rt]);
+    for (int r = 0; r < 16; ++r) hv[rt][r] = rs ? 0.0f : hv[rt][r];
+    put16<IROW, IPLANE>(RB + rt * IIMG, j, fb, hv[rt]);
   }
+  STAMP(0);
   __syncthreads();
+  STAMP(1);
 
   // the GRU's first two batches of fragments (gate column tiles of this wave: r -> tile w, z -> 4 + w, n -> 8 + w)
   constexpr int DG = 2;
@@ -232,6 +297,7 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(2);
     __syncthreads();  // every wave has read the x images: region A becomes the E images
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -241,7 +307,9 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
       put16<IROW, IPLANE>(RA + rt * nh.abytes, j, fb, e);
     }
   }
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
 
   // ---- GRU cell (flax GRUCell): r = s(W_ir e + b_ir + W_hr h), z likewise, n = tanh(W_in e + b_in + r (W_hn h + b_hn))
   float hn[RT][16];
@@ -286,23 +354,32 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
     // post_torso's fragments travel during the gate arithmetic
 #pragma unroll
     for (int d = 0; d < DP; ++d) rp[d] = load_frag(Ppost, w * 8 + d, lane);
+    float hp[RT][16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) load_hp(rt, hp[rt]);
+    STAMP(5);
     __syncthreads();  // every wave has read the masked-h images: region B becomes the new-h images
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const bool live = it0 + rt < ntiles;
-      float* hout = nt.h_out + ((long)(it0 + rt) * MLP_H + fb) * 32 + j;
+      const bool rs = (rs_bits >> rt) & 1u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float rr = sigm(ga[rt][1][r]);
         const float zz = sigm(ga[rt][2][r]);
         const float nn = tanh_(ga[rt][0][r] + rr * ga[rt][3][r]);
-        hn[rt][r] = (1.0f - zz) * nn + zz * hp[rt][r];
-        if (live) hout[((r & 3) + 8 * (r >> 2)) * 32] = hn[rt][r];
+        hn[rt][r] = (1.0f - zz) * nn + zz * (rs ? 0.0f : hp[rt][r]);
+      }
+      if (it0 + rt < ntiles) {  // (one uniform branch per tile, straight-line stores)
+        float* hout = nt.h_out + ((long)(it0 + rt) * MLP_H + fb) * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hout[((r & 3) + 8 * (r >> 2)) * 32] = hn[rt][r];
       }
       put16<IROW, IPLANE>(RB + rt * IIMG, j, fb, hn[rt]);
     }
   }
+  STAMP(6);
   __syncthreads();
+  STAMP(7);
 
   // ---- post_torso + partial head
   {
@@ -323,92 +400,141 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      float part[NO];
+      // relu, split, and the packed groups ARE the operand of the head product (groups (2s, 2s+1) = k-step s)
+      half4 ph[4], pl[4];
 #pragma unroll
-      for (int o = 0; o < NO; ++o) part[o] = 0.0f;
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fmaxf(acc[rt][r], 0.0f);
-        const float* w3 = W3s + (fb + (r & 3) + 8 * (r >> 2)) * NO;
+        for (int e = 0; e < 4; ++e) {
+          _Float16 a, b;
+          h2::split1(fmaxf(acc[rt][4 * g + e], 0.0f), a, b);
+          ph[g][e] = a;
+          pl[g][e] = b;
+        }
+      f32x16 yacc;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) part[o] = fmaf(pv, w3[o], part[o]);
+      for (int q = 0; q < 16; ++q) yacc[q] = 0.0f;
+#pragma unroll
+      for (int sgm = 0; sgm < 2; ++sgm) {
+        Frag b;
+        b.hi = __builtin_shufflevector(ph[2 * sgm], ph[2 * sgm + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        b.lo = __builtin_shufflevector(pl[2 * sgm], pl[2 * sgm + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        yacc = h2::mfma3(W3h[sgm], b, yacc);
       }
+      // partial logits of this wave: register q of lane (row j, half h) is output (q&3) + 8(q>>2) + 4h
 #pragma unroll
-      for (int o = 0; o < NO; ++o) {
-        const float v = part[o] + __shfl_xor(part[o], 32, 64);
-        if (h == 0) YP[((rt * 4 + w) * NO + o) * 32 + j] = v;
+      for (int q = 0; q < 16; ++q) {
+        const int o = (q & 3) + 8 * (q >> 2) + 4 * h;
+        if ((q & 3) + 8 * (q >> 2) < NO) {
+          if (o < NO) YP[((rt * 4 + w) * NO + o) * 32 + j] = yacc[q] * h2::W3_UNSCALE;
+        }
       }
     }
   }
+  STAMP(8);
   __syncthreads();
+  STAMP(9);
 
-  // ---- epilogue: wave rt serves row tile rt, one lane per row
-  if (w < RT && h == 0 && it0 + w < ntiles) {
-    const int rt = w;
-    const int row = (it0 + rt) * 32 + j;
-    const float* yp = YP + (rt * 4) * NO * 32 + j;
-    float y[NO];
+  // ---- epilogue: eight lanes per row (all 32 rows of a tile at once), lane l8 owns outputs l8, l8 + 8, ...
+  constexpr int OPL = NO / 8;
+  const int l8 = lane & 7, erow = tid >> 3;
+  auto add_op = [](float a, float b) { return a + b; };
+  auto max_op = [](float a, float b) { return fmaxf(a, b); };
+  auto min_op = [](float a, float b) { return fminf(a, b); };
+  const float* const B3 = BS + 6 * MLP_H;
+#pragma unroll 1
+  for (int rt = 0; rt < RT; ++rt) {
+    if (it0 + rt >= ntiles) break;
+    const int row = (it0 + rt) * 32 + erow;
+    float y[OPL];
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
-      y[o] = (((yp[(0 * NO + o) * 32] + yp[(1 * NO + o) * 32]) + yp[(2 * NO + o) * 32]) + yp[(3 * NO + o) * 32]) +
-             ((o < no) ? bhead[o] : 0.0f);
+    for (int k = 0; k < OPL; ++k) {
+      const int o = l8 + 8 * k;
+      const float* yp = YP + ((rt * 4) * NO + o) * 32 + erow;
+      y[k] = (((yp[0] + yp[NO * 32]) + yp[2 * NO * 32]) + yp[3 * NO * 32]) + B3[o];
+    }
     if (!ACTOR) {
-      for (int b = 0; b < out.vbroadcast; ++b) out.value[(long)row * out.vbroadcast + b] = y[0];
+      if (l8 == 0)
+        for (int b = 0; b < out.vbroadcast; ++b) out.value[(long)row * out.vbroadcast + b] = y[0];
     } else if (out.action_f != nullptr) {
+      // ContinuousActionHead (networks.py:127-169): same noise stream as mava_seq_sample_continuous_f32
       const float* const log_std = bhead + no;
       const uint32_t gid = out.row_offset + (uint32_t)row;
       float lp = 0.0f;
 #pragma unroll
-      for (int o = 0; o < NO; ++o) {
+      for (int k = 0; k < OPL; ++k) {
+        const int o = l8 + 8 * k;
         if (o < no) {
           const float sc = tn::scale_of(log_std[o]);
           const float eps = out.greedy ? 0.0f : tn::noise(gid, out.step, o, tn::STREAM_SAMPLE, out.seed_lo, out.seed_hi);
-          const float a = tanhf(fmaf(sc, eps, y[o]));
-          lp += tn::log_prob(a, y[o], sc).lp;
+          const float a = tanhf(fmaf(sc, eps, y[k]));
+          lp += tn::log_prob(a, y[k], sc).lp;
           out.action_f[(long)row * no + o] = a;
         }
       }
-      out.log_prob[row] = lp;
+      lp = h2::group_allreduce<8>(lp, add_op);
+      if (l8 == 0) out.log_prob[row] = lp;
     } else {
-      Categorical<NO> cat;
-      cat.build(y, out.mask != nullptr ? (out.mask + (long)row * no) : nullptr, no);
-      int a = 0;
+      // masked Categorical (networks.py:116-124, distributions.py:146-165) + Gumbel-max: argmax_o z[o] - log(-log(u_o)),
+      // first index wins ties (same stream as mava_seq_sample_f32)
+      float z[OPL], sc[OPL];
+      float mx = -FLT_MAX;
+      const uint32_t gid = out.row_offset + (uint32_t)row;
+#pragma unroll
+      for (int k = 0; k < OPL; ++k) {
+        const int o = l8 + 8 * k;
+        const bool legal = (o < no) && (out.mask == nullptr || out.mask[(long)row * no + o] != 0);
+        z[k] = legal ? y[k] : -FLT_MAX;
+        mx = fmaxf(mx, z[k]);
+      }
+      mx = h2::group_allreduce<8>(mx, max_op);
+      float se = 0.0f;
+#pragma unroll
+      for (int k = 0; k < OPL; ++k) se += expf(z[k] - mx);
+      se = h2::group_allreduce<8>(se, add_op);
+      const float lse = mx + logf(se);
       float best = -FLT_MAX;
-      if (out.greedy) {
 #pragma unroll
-        for (int o = 0; o < NO; ++o)
-          if (o < no && cat.z[o] > best) { best = cat.z[o]; a = o; }
-      } else {
-        const uint32_t gid = out.row_offset + (uint32_t)row;
-#pragma unroll
-        for (int c = 0; c < (NO + 3) / 4; ++c) {
-          Philox4 rnd = philox4x32_10(gid, out.step, (uint32_t)c, 0x504f4c49u /*"POLI"*/, out.seed_lo, out.seed_hi);
-          const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int o = 4 * c + q;
-            if (o < NO && o < no) {
-              const float sc = cat.z[o] - logf(-logf(u01_open(wds[q])));
-              if (sc > best) { best = sc; a = o; }
-            }
+      for (int k = 0; k < OPL; ++k) {
+        const int o = l8 + 8 * k;
+        sc[k] = -FLT_MAX;
+        if (o < no) {
+          if (out.greedy) {
+            sc[k] = z[k];
+          } else {
+            Philox4 rnd = philox4x32_10(gid, out.step, (uint32_t)(o >> 2), 0x504f4c49u /*"POLI"*/, out.seed_lo, out.seed_hi);
+            const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+            sc[k] = z[k] - logf(-logf(u01_open(wds[o & 3])));
           }
         }
+        best = fmaxf(best, sc[k]);
       }
+      best = h2::group_allreduce<8>(best, max_op);
+      float ai = 1e9f;  // lowest output index that reaches the best score
+#pragma unroll
+      for (int k = OPL - 1; k >= 0; --k)
+        if (sc[k] == best && l8 + 8 * k < no) ai = (float)(l8 + 8 * k);
+      ai = h2::group_allreduce<8>(ai, min_op);
+      const int a = ai < 1e8f ? (int)ai : 0;
       float lp = 0.0f;
 #pragma unroll
-      for (int o = 0; o < NO; ++o)
-        if (o == a) lp = cat.logp[o];
-      out.action[row] = a;
-      out.log_prob[row] = lp;
+      for (int k = 0; k < OPL; ++k)
+        if (l8 + 8 * k == a) lp = z[k] - lse;
+      lp = h2::group_allreduce<8>(lp, add_op);
+      if (l8 == 0) {
+        out.action[row] = a;
+        out.log_prob[row] = lp;
+      }
     }
   }
+  STAMP_FLUSH();
 }
 
 template <int NOA, int RT>
 __global__ __launch_bounds__(256, 1) void rec_step_h2_kernel(NetH2 actor, NetH2 critic, int ngrp_actor, RecStepOut out) {
   extern __shared__ __attribute__((aligned(16))) u8 lds_h2[];
   if ((int)blockIdx.x < ngrp_actor) rec_step_h2_body<NOA, true, RT>(actor, out, lds_h2, (int)blockIdx.x);
-  else rec_step_h2_body<1, false, RT>(critic, out, lds_h2, (int)blockIdx.x - ngrp_actor);
+  else rec_step_h2_body<8, false, RT>(critic, out, lds_h2, (int)blockIdx.x - ngrp_actor);  // (one output of the 8-wide head tile)
 }
 
 long pack_bytes(int din) { return (long)(4 * ((din + 15) / 16) + 96 + 96 + 32) * 2048; }
@@ -422,8 +548,8 @@ void setup(NetH2& n) {
 
 template <int NOA, int RT>
 int launch_step(const NetH2& a, const NetH2& c, int ga, int gc, const RecStepOut& so, hipStream_t s) {
-  const size_t la = (size_t)RT * (a.abytes + IIMG) + (size_t)(MLP_H * NOA + RT * 4 * NOA * 32 + 6 * MLP_H) * 4;
-  const size_t lc = (size_t)RT * (c.abytes + IIMG) + (size_t)(MLP_H + RT * 4 * 32 + 6 * MLP_H) * 4;
+  const size_t la = (size_t)RT * (a.abytes + IIMG) + (size_t)(RT * 4 * NOA * 32 + 6 * MLP_H + NOA) * 4;
+  const size_t lc = (size_t)RT * (c.abytes + IIMG) + (size_t)(RT * 4 * 8 * 32 + 6 * MLP_H + 8) * 4;
   const size_t lb = la > lc ? la : lc;
   if (lb > 163840) return 1;
   static bool attr_set = false;
@@ -437,6 +563,12 @@ int launch_step(const NetH2& a, const NetH2& c, int ga, int gc, const RecStepOut
 }
 
 }  // namespace
+
+#ifdef MAVA_STAMPS
+extern "C" int mava_debug_set_step_stamps(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_step_stamps), &p, sizeof(p));
+}
+#endif
 
 extern "C" long mava_rec_step_pack_bytes(int din) { return pack_bytes(din); }
 

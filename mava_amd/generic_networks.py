@@ -196,7 +196,7 @@ class GenericNet:
 
     @staticmethod
     def _xty(x_ptr: int, x_ld: int, K: int, y: torch.Tensor, N: int, rows: int, slabs: torch.Tensor, gw: torch.Tensor,
-             gb: Optional[torch.Tensor], scale: float, accumulate: bool) -> None:
+             gb: Optional[torch.Tensor], scale: float, accumulate: bool, gb_accumulate: Optional[bool] = None) -> None:
         """gw (K x N) (+)= scale * x^T y ; gb (N) (+)= scale * colsum(y)"""
         from . import ops
 
@@ -217,22 +217,28 @@ class GenericNet:
                     dst.copy_(blk.view(kb, nb))
                 if want_b:
                     tail = slabs[:, kb * nb : kb * nb + nb].contiguous()
-                    ops.slab_reduce(tail, nb, gb[n0 : n0 + nb], accumulate=accumulate)
+                    ops.slab_reduce(tail, nb, gb[n0 : n0 + nb], accumulate=accumulate if gb_accumulate is None else gb_accumulate)
 
     # ----------------------------------------------------------------------------------- forward / backward
     def workspace(self, rows: int, device, training: bool) -> "GenericWorkspace":
         return GenericWorkspace(self, rows, device, training)
 
-    def forward(self, flat: torch.Tensor, ws: "GenericWorkspace", x_ext: torch.Tensor, x_share: int, idx, Rm: int, E: int, A: int,
-                T: int = 1) -> List[torch.Tensor]:
+    def forward(self, flat: torch.Tensor, ws: "GenericWorkspace", x_ext: Optional[torch.Tensor], x_share: int, idx, Rm: int, E: int,
+                A: int, T: int = 1, x_t32: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         """x_ext: external row-major (T, E, A / x_share, din) source, gathered like mava_rec_dense_f32's row-major input
-        (batch row q = t*Rm + m, m = local_env*A + agent, env = idx[local_env] or identity).  Returns the heads' T32 outputs."""
+        (batch row q = t*Rm + m, m = local_env*A + agent, env = idx[local_env] or identity); or x_t32: the input already as a
+        T32 matrix of din features (the recurrent post torso reads the hidden states).  Returns the heads' T32 outputs, or
+        [features] for a torso without heads."""
         L, s = lib(), stream_ptr()
         rows = T * Rm
         assert rows == ws.rows
-        kp = ws.kp
-        check(L.mava_rec_gather_t32_f32(ptr(x_ext), ptr(idx), Rm, E, A, x_share, self.din, self.din, rows, kp, ptr(ws.xin), s), "gather")
-        cur, cur_ld, cur_rows = ws.xin, kp, rows
+        if x_t32 is not None:
+            ws.x_src, ws.x_src_ld = x_t32, self.din
+        else:
+            check(L.mava_rec_gather_t32_f32(ptr(x_ext), ptr(idx), Rm, E, A, x_share, self.din, self.din, rows, ws.kp, ptr(ws.xin), s),
+                  "gather")
+            ws.x_src, ws.x_src_ld = ws.xin, ws.kp
+        cur, cur_ld, cur_rows = ws.x_src, ws.x_src_ld, rows
         for i, ly in enumerate(self.layers):
             w = flat[ly.w : ly.w + ly.K * ly.N]
             b = flat[ly.b : ly.b + ly.N]
@@ -251,6 +257,8 @@ class GenericNet:
             check(L.mava_t32_flatten_f32(ptr(cur), rows, self.P_last, self.C_last, 1, ptr(ws.feat), s), "flatten")
             cur, cur_ld = ws.feat, self.feat
         ws.feat_in = cur
+        if not self.heads:
+            return [cur]
         outs = []
         for h, hd in enumerate(self.heads):
             self._dense(cur.data_ptr(), cur_ld, hd.K, flat[hd.w : hd.w + hd.K * hd.N], flat[hd.b : hd.b + hd.N], ws.out[h], hd.N, rows)
@@ -258,12 +266,16 @@ class GenericNet:
         return outs
 
     def backward(self, flat: torch.Tensor, ws: "GenericWorkspace", d_outs: List[torch.Tensor], grad_out: torch.Tensor, accumulate: bool,
-                 grad_scale: float = 1.0) -> None:
-        """d_outs[h]: T32 gradient w.r.t. head h's output (in units of grad_scale).  grad_out: flat gradient (true units)."""
+                 grad_scale: float = 1.0, d_feat: Optional[torch.Tensor] = None, dx_out: Optional[torch.Tensor] = None) -> None:
+        """d_outs[h]: T32 gradient w.r.t. head h's output (in units of grad_scale); a torso without heads takes d_feat, the
+        gradient w.r.t. its features, instead.  grad_out: flat gradient (true units).  dx_out: receives the gradient w.r.t.
+        the (T32) input when given."""
         L, s = lib(), stream_ptr()
         rows = ws.rows
         inv = 1.0 / grad_scale
         feat, feat_ld = ws.feat_in, self.feat
+        if d_feat is not None:
+            ws.dfeat.copy_(d_feat[: ws.dfeat.numel()])
         # heads
         for h, hd in enumerate(self.heads):
             self._xty(feat.data_ptr(), feat_ld, hd.K, d_outs[h], hd.N, rows, ws.slabs, grad_out[hd.w : hd.w + hd.K * hd.N],
@@ -287,14 +299,18 @@ class GenericNet:
             if ly.kind == "conv":
                 x_ptr, x_ld = ws.col[i].data_ptr(), ly.K
             elif i == 0:
-                x_ptr, x_ld = ws.xin.data_ptr(), ws.kp
+                x_ptr, x_ld = ws.x_src.data_ptr(), ws.x_src_ld
             else:
                 x_ptr, x_ld = ws.y[i - 1].data_ptr(), self.layers[i - 1].N
             self._xty(x_ptr, x_ld, ly.K, ws.dzin[i], ly.N, lrows, ws.slabs, grad_out[ly.w : ly.w + ly.K * ly.N],
                       grad_out[ly.b : ly.b + ly.N], inv, accumulate)
-            if i == 0:
+            if i == 0 and dx_out is None:
                 break
             wt = flat[ly.w : ly.w + ly.K * ly.N].view(ly.K, ly.N).t().contiguous()
+            if i == 0:  # gradient w.r.t. the T32 input (dense first layer only)
+                assert ly.kind == "dense", "dx_out is implemented for dense first layers"
+                self._dense(ws.dzin[0].data_ptr(), ly.N, ly.N, wt, None, dx_out, ly.K, lrows)
+                break
             if ly.kind == "conv":
                 self._dense(ws.dzin[i].data_ptr(), ly.N, ly.N, wt, None, ws.dcol[i], ly.K, lrows)
                 H, W, C, k, st = ly.geo

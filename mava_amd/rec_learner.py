@@ -93,6 +93,9 @@ class RecLearner:
         # rec_mappo.py:361-363: the action head of the configuration, sized by the env's action dimension
         action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
         self.continuous = type(action_head).__name__ == "ContinuousActionHead"
+        if self.continuous and not getattr(action_head, "independent_std", True):
+            raise NotImplementedError("ContinuousActionHead(independent_std=False) is built for the feed-forward systems "
+                                      "(general network path), not for the recurrent ones")
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
             self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
@@ -122,15 +125,24 @@ class RecLearner:
                 rep.set_critic_rows(1)
 
         net = config.network
-        mk = lambda c: MLPTorso(**{k: v for k, v in c.items() if k != "_target_"})
+        from .generic_networks import GenericMLPTorso
+
+        def torsos(nc):
+            """(pre, post) of one network: network/rnn.yaml's [128] relu torsos run on the dedicated kernels; any other
+            MLPTorso configuration (layer sizes, tanh, layer norm) makes BOTH torsos of that network general ones."""
+            cfgs = [{k: v for k, v in c.items() if k != "_target_"} for c in (nc.pre_torso, nc.post_torso)]
+            for c, raw in zip(cfgs, (nc.pre_torso, nc.post_torso)):
+                if str(dict(raw).get("_target_", "MLPTorso")).endswith("CNNTorso"):
+                    raise NotImplementedError("CNN torsos are built for the feed-forward systems (network=cnn), not for rcnn")
+            default = all(list(c.get("layer_sizes", [128])) == [128] and c.get("activation", "relu") == "relu"
+                          and not c.get("use_layer_norm", False) for c in cfgs)
+            return tuple((MLPTorso if default else GenericMLPTorso)(**c) for c in cfgs)
+
+        mk = lambda c: None
         hsd = int(net.get("hidden_state_dim", 128))
-        self.actor_network = RecurrentActor(mk(net.actor_network.pre_torso), mk(net.actor_network.post_torso),
-                                            action_head, self.Oa, hsd)
-        self.critic_network = RecurrentValueNet(mk(net.critic_network.pre_torso), mk(net.critic_network.post_torso),
-                                                centralised_critic, self.Oc, hsd)
-        for t in (net.actor_network.pre_torso, net.actor_network.post_torso, net.critic_network.pre_torso,
-                  net.critic_network.post_torso):
-            mk(t).require([128])
+        self.actor_network = RecurrentActor(*torsos(net.actor_network), action_head, self.Oa, hsd)
+        self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd)
+        self.generic_nets = self.actor_network.generic or self.critic_network.generic
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
         self.P = self.Pa + self.Pc
 
@@ -147,7 +159,7 @@ class RecLearner:
         # the backward chain runs in units of a power of two near the row count (mava_seq_actor_loss_f32: f16 range)
         self.grad_scale = float(2 ** math.ceil(math.log2(self.T * self.Rm)))
         # f16x2: both networks' weights pre-split in MFMA-fragment order for the fused acting step (re-packed per rollout)
-        self.fused_out = (self.matmul_mode == "f16x2" and not self.continuous and self.nA <= 16
+        self.fused_out = (self.matmul_mode == "f16x2" and not self.continuous and self.nA <= 16 and not self.generic_nets
                           and os.environ.get("MAVA_REC_FUSED_OUT", "1") != "0")
         self.pack_a = torch.empty(lib().mava_rec_step_pack_bytes(self.Oa), dtype=torch.uint8, device=d)
         self.pack_c = torch.empty(lib().mava_rec_step_pack_bytes(self.Oc), dtype=torch.uint8, device=d)
@@ -223,7 +235,7 @@ class RecLearner:
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
             rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
             rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
-        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0"
+        fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0" and not self.generic_nets  # (fused step: default torsos)
         packed = fused and self.matmul_mode == "f16x2" and self.nA <= 16
         if packed:  # the parameters are constant during a rollout: split them once (rec_step_h2.hip)
             check(lib().mava_rec_step_pack_f32(ptr(pa), self.Oa, ptr(self.pack_a), stream_ptr()), "mava_rec_step_pack_f32")

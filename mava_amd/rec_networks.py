@@ -56,11 +56,29 @@ class RecWorkspace:
 class _RecurrentNet:
     head_scale = 1.0
 
-    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128):
+    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None):
         if hidden_state_dim != H:
             raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
         self.din, self.n_out = int(din), int(n_out)
-        self.segments, self.num_params = rec_segments(self.din, self.n_out)
+        # Torsos other than network/rnn.yaml's [128] relu (any layer sizes, tanh, layer norm: mava/networks.py:39-58) run on
+        # the general layer kernels (mava_amd/generic_networks.py) around the same GRU scans; the fused acting step and the
+        # fused output path are for the default torsos only.
+        from .generic_networks import GenericMLPTorso, GenericNet
+
+        self.generic = isinstance(pre_torso, GenericMLPTorso) or isinstance(post_torso, GenericMLPTorso)
+        if self.generic:
+            self.pre = GenericNet(pre_torso, self.din, [])
+            self.post = GenericNet(post_torso, H, [("head", self.n_out, self.head_scale)])
+            Np, off = self.pre.feat, self.pre.num_params
+            segs = []
+            for name, shape in (("Wi", (Np, G3)), ("bi", (G3,)), ("Wh", (H, G3)), ("bhn", (H,))):
+                segs.append((name, shape, off))
+                off += math.prod(shape)
+            self.post_off = off
+            self.segments, self.num_params = segs, off + self.post.num_params
+            self.Np = Np
+        else:
+            self.segments, self.num_params = rec_segments(self.din, self.n_out)
         self.num_net_params = self.num_params  # the continuous actor appends log_std(n_out) behind the network
         self.off = {n: (o, s) for n, s, o in self.segments}
 
@@ -73,6 +91,15 @@ class _RecurrentNet:
         orthogonal recurrent kernels, zero biases), orthogonal(head_scale) head."""
         gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
         flat = torch.zeros(self.num_params, dtype=torch.float32)
+        if self.generic:
+            flat[: self.pre.num_params].copy_(self.pre.init_flat(seed))
+            flat[self.post_off : self.post_off + self.post.num_params].copy_(self.post.init_flat(seed + 1))
+            self.seg(flat, "Wi").copy_(torch.randn((self.Np, G3), generator=gen) / math.sqrt(self.Np))
+            for g in range(3):
+                blk = torch.empty(H, H)
+                _orthogonal_(blk, 1.0, gen)
+                self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(blk)
+            return flat.to(device) if device is not None else flat
         _orthogonal_(self.seg(flat, "Wpre"), math.sqrt(2.0), gen)
         self.seg(flat, "Wi").copy_(torch.randn((H, G3), generator=gen) / math.sqrt(H))
         for g in range(3):
@@ -86,6 +113,17 @@ class _RecurrentNet:
     def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
         ex = (lambda v: v.expand(*lead, *v.shape)) if lead else (lambda v: v)
         Wi, bi, Wh = self.seg(flat, "Wi"), self.seg(flat, "bi"), self.seg(flat, "Wh")
+        if self.generic:
+            cell = {
+                "ir": {"kernel": ex(Wi[:, :H]), "bias": ex(bi[:H])}, "iz": {"kernel": ex(Wi[:, H : 2 * H]), "bias": ex(bi[H : 2 * H])},
+                "in": {"kernel": ex(Wi[:, 2 * H :]), "bias": ex(bi[2 * H :])}, "hr": {"kernel": ex(Wh[:, :H])},
+                "hz": {"kernel": ex(Wh[:, H : 2 * H])}, "hn": {"kernel": ex(Wh[:, 2 * H :]), "bias": ex(self.seg(flat, "bhn"))},
+            }
+            fpost = flat[self.post_off : self.post_off + self.post.num_params]
+            tree = {"pre_torso": self.pre.torso_tree(flat[: self.pre.num_params], lead), "ScannedRNN_0": {"GRUCell_0": cell},
+                    "post_torso": self.post.torso_tree(fpost, lead)}
+            tree.update(self._head_tree(self.post.head_leaf(fpost, 0, lead)))
+            return {"params": tree}
         cell = {
             "ir": {"kernel": ex(Wi[:, :H]), "bias": ex(bi[:H])},
             "iz": {"kernel": ex(Wi[:, H : 2 * H]), "bias": ex(bi[H : 2 * H])},
@@ -108,6 +146,8 @@ class _RecurrentNet:
         taken, like unreplicate_n_dims, mava/utils/jax_utils.py:52-59) into the flat layout the kernels read."""
         p = tree["params"]
         cell = p["ScannedRNN_0"]["GRUCell_0"]
+        if self.generic:
+            return self._flat_from_tree_generic(p, cell, out)
         if "action_head" in p:  # discrete: Dense_0 (networks.py:106); continuous: mean + log_std (networks.py:138-141)
             head = p["action_head"]["mean"] if "mean" in p["action_head"] else p["action_head"]["Dense_0"]
         else:
@@ -135,6 +175,43 @@ class _RecurrentNet:
         if "action_head" in p and "log_std" in p["action_head"]:
             flat[self.num_net_params : self.num_net_params + self.n_out].copy_(leaf(p["action_head"]["log_std"], (self.n_out,)))
         return flat
+
+    def _flat_from_tree_generic(self, p, cell, out):
+        def leaf(v, shape):
+            v = torch.as_tensor(v)
+            while v.dim() > len(shape):
+                v = v[0]
+            return v.reshape(shape)
+
+        if "action_head" in p:
+            head = p["action_head"]["mean"] if "mean" in p["action_head"] else p["action_head"]["Dense_0"]
+        else:
+            head = p["Dense_0"]
+        dev = torch.as_tensor(cell["hr"]["kernel"]).device
+        flat = out if out is not None else torch.empty(self.num_params, dtype=torch.float32, device=dev)
+        self.pre.load_torso_tree(p["pre_torso"], flat[: self.pre.num_params])
+        fpost = flat[self.post_off : self.post_off + self.post.num_params]
+        self.post.load_torso_tree(p["post_torso"], fpost)
+        self.post.load_head_leaf(head, 0, fpost)
+        for g, (ik, hk) in enumerate((("ir", "hr"), ("iz", "hz"), ("in", "hn"))):
+            self.seg(flat, "Wi")[:, g * H : (g + 1) * H].copy_(leaf(cell[ik]["kernel"], (self.Np, H)))
+            self.seg(flat, "bi")[g * H : (g + 1) * H].copy_(leaf(cell[ik]["bias"], (H,)))
+            self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(leaf(cell[hk]["kernel"], (H, H)))
+        self.seg(flat, "bhn").copy_(leaf(cell["hn"]["bias"], (H,)))
+        if "action_head" in p and "log_std" in p["action_head"]:
+            flat[self.num_net_params : self.num_net_params + self.n_out].copy_(leaf(p["action_head"]["log_std"], (self.n_out,)))
+        return flat
+
+    def _gen_ws(self, ws: RecWorkspace, training: bool):
+        """General-path workspaces of this network inside a RecWorkspace (created on first use)."""
+        key = (id(self), training)
+        if not hasattr(ws, "gen"):
+            ws.gen = {}
+        if key not in ws.gen:
+            dev = ws.hs.device
+            ws.gen[key] = (self.pre.workspace(ws.rows, dev, training), self.post.workspace(ws.rows, dev, training),
+                           torch.empty(ws.rows * self.Np, device=dev) if training else None)
+        return ws.gen[key]
 
     def _apply_sequence(self, params: Any, hstate: torch.Tensor, x: torch.Tensor, done: torch.Tensor):
         """Shared body of RecurrentActor.apply / RecurrentValueNet.apply: x (T, E, A, din), done (T, E, A),
@@ -168,6 +245,21 @@ class _RecurrentNet:
         L = lib()
         s = stream_ptr()
         W = lambda n: ptr(self.seg(flat, n))
+        if self.generic:
+            from .generic_networks import GenericNet
+
+            wpre, wpost, _ = self._gen_ws(ws, training)
+            feat = self.pre.forward(flat[: self.pre.num_params], wpre, x_ext, x_share, idx, Rm, E, A, T=T)[0]
+            GenericNet._dense(feat.data_ptr(), self.Np, self.Np, self.seg(flat, "Wi"), self.seg(flat, "bi"), ws.gi, G3, rows, what="rec_dense(gi)")
+            launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
+                   ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
+            if stop_after_scan:
+                raise NotImplementedError("the fused output path serves the default torsos only")
+            y = self.post.forward(flat[self.post_off : self.post_off + self.post.num_params], wpost, None, 1, None, rows, rows, 1,
+                                  x_t32=ws.hs)[0]
+            dst = ws.y if y_out is None else y_out  # (the losses / sampling kernels read the workspace's output buffer)
+            dst.view(-1)[: y.numel()].copy_(y)
+            return dst
         # pre-torso: inputs wider than 384 are consumed in column blocks (accumulating products; the weight
         # slice of one block stays register-resident), the ReLU rides on the last block
         din, Wpre = self.din, self.seg(flat, "Wpre")
@@ -224,6 +316,32 @@ class _RecurrentNet:
         L = lib()
         s = stream_ptr()
         n_out = self.n_out
+        if self.generic:
+            from .generic_networks import GenericNet
+
+            wpre, wpost, dfeat = self._gen_ws(ws, True)
+            fpost = flat[self.post_off : self.post_off + self.post.num_params]
+            gpost = grad_out[self.post_off : self.post_off + self.post.num_params]
+            self.post.backward(fpost, wpost, [ws.dy], gpost, accumulate, grad_scale, dx_out=ws.dh_out)
+            launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
+                   ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
+            o = lambda n: self.off[n][0]
+            Np = self.Np
+            GenericNet._xty(wpre.feat_in.data_ptr(), Np, Np, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * G3],
+                            grad_out[o("bi") : o("bi") + G3], 1.0 / grad_scale, accumulate)
+            # dW_h, and db_hn = the n part of colsum(dgh) (taken from a scratch vector: r and z have no hidden-side bias)
+            tmp_b = torch.empty(G3, device=flat.device)
+            GenericNet._xty(ws.hprev.data_ptr(), H, H, ws.dgh, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
+                            1.0 / grad_scale, accumulate, gb_accumulate=False)
+            gbhn = grad_out[o("bhn") : o("bhn") + H]
+            if accumulate:
+                gbhn.add_(tmp_b[2 * H :])
+            else:
+                gbhn.copy_(tmp_b[2 * H :])
+            WiT = self.seg(flat, "Wi").t().contiguous()
+            GenericNet._dense(ws.dgi.data_ptr(), G3, G3, WiT, None, dfeat, Np, rows, what="rec_dense(bwd)")
+            self.pre.backward(flat[: self.pre.num_params], wpre, [], grad_out[: self.pre.num_params], accumulate, grad_scale, d_feat=dfeat)
+            return
         # transposed weights for the dX = dY W^T products (tiny, re-materialised per call)
         WheadT = self.seg(flat, "Whead").t().contiguous()
         WpostT = self.seg(flat, "Wpost").t().contiguous()
@@ -274,7 +392,7 @@ class RecurrentActor(_RecurrentNet):
 
     def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head, obs_dim: int,
                  hidden_state_dim: int = 128):
-        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim)
+        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim, pre_torso, post_torso)
         self.continuous = isinstance(action_head, ContinuousActionHead)
         if self.continuous:
             self.num_params += self.n_out
@@ -312,7 +430,7 @@ class RecurrentValueNet(_RecurrentNet):
 
     def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, centralised_critic: bool, input_dim: int,
                  hidden_state_dim: int = 128):
-        super().__init__(input_dim, 1, hidden_state_dim)
+        super().__init__(input_dim, 1, hidden_state_dim, pre_torso, post_torso)
         self.centralised_critic = centralised_critic
 
     def _head_tree(self, head):

@@ -63,8 +63,8 @@ def param_count(spec) -> int:
     return n + spec["raw_tail"]
 
 
-def forward(flat: torch.Tensor, spec, x: torch.Tensor) -> List[torch.Tensor]:
-    """x: (rows, din).  Returns the heads' outputs [(rows, n_out)]."""
+def forward(flat: torch.Tensor, spec, x: torch.Tensor, features: bool = False):
+    """x: (rows, din).  Returns the heads' outputs [(rows, n_out)], or the torso's features when `features`."""
     off = 0
 
     def take(shape):
@@ -99,6 +99,8 @@ def forward(flat: torch.Tensor, spec, x: torch.Tensor) -> List[torch.Tensor]:
             h = _act(h, spec["act"])
             H, W, C = Ho, Wo, co
         feat = h.reshape(h.shape[0], -1)  # jax.lax.collapse(x, -3): (H, W, C) row-major
+    if features:
+        return feat
     outs = []
     for no in spec["heads"]:
         w, b = take((feat.shape[1], no)), take((no,))

@@ -22,7 +22,7 @@ from .synth_env import SynthRware
 class OracleRecLearner:
     def __init__(self, *, E, A, O, nA, T, K, M, U=1, centralised=True, seed=42, gamma=0.99, gae_lambda=0.95, clip_eps=0.2,
                  ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, actor_lr=2.5e-4, critic_lr=2.5e-4, time_limit=500, state_dim=0,
-                 continuous=False, reward_mode="random"):
+                 continuous=False, reward_mode="random", actor_net=None, critic_net=None):
         self.continuous = continuous  # ContinuousActionHead (oracle/tanh_normal.py): nA = action dimensions
         self.ent_step = 0
         self.E, self.A, self.O, self.nA, self.T, self.K, self.M, self.U = E, A, O, nA, T, K, M, U
@@ -30,6 +30,10 @@ class OracleRecLearner:
         self.h = dict(gamma=gamma, lam=gae_lambda, clip=clip_eps, ent=ent_coef, vf=vf_coef, mgn=max_grad_norm, lrs=(actor_lr, critic_lr))
         self.Oa = A + O
         self.Oc = (state_dim if state_dim > 0 else A * O) if centralised else self.Oa
+        # network descriptions handed to oracle/rec_oracle.py: the input width (network/rnn.yaml's default torsos) or a
+        # rec_oracle.rec_spec(...) dict (other layer sizes / tanh / layer norm)
+        self.Na = actor_net if actor_net is not None else self.Oa
+        self.Nc = critic_net if critic_net is not None else self.Oc
         self.envs = [SynthRware(E, A, O, nA, time_limit, seed, env_offset=u * E, state_dim=state_dim, reward_mode=reward_mode)
                      for u in range(U)]
         self.obs = [e.reset(0) for e in self.envs]
@@ -58,8 +62,8 @@ class OracleRecLearner:
             step = self.t_global + t
             av, cx, mask = obs["agents_view"].astype(np.float64), self._cx(obs), obs["action_mask"]
             d_in = self.dones[u].reshape(E * A)
-            n_net = ro.rec_param_count(self.Oa, nA)
-            y, _, self.ha[u] = ro.rec_forward(self.pa[:n_net], self.Oa, nA, av.reshape(1, E * A, -1), d_in[None], self.ha[u])
+            n_net = ro.rec_param_count(self.Na, nA)
+            y, _, self.ha[u] = ro.rec_forward(self.pa[:n_net], self.Na, nA, av.reshape(1, E * A, -1), d_in[None], self.ha[u])
             if self.continuous:
                 eps = tn.normal_noise(self.seed, step, E * A, nA, tn.STREAM_SAMPLE, row_offset=u * E * A)
                 action = tn.sample(y[0], self.pa[n_net:], eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
@@ -70,7 +74,7 @@ class OracleRecLearner:
                 action = po.gumbel_argmax(z, philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=u * E * A))
                 lp = po.log_softmax(z)[np.arange(E * A), action]
                 action = action.reshape(E, A)
-            v, _, self.hc[u] = ro.rec_forward(self.pc, self.Oc, 1, cx.reshape(1, E * A, -1), d_in[None], self.hc[u])
+            v, _, self.hc[u] = ro.rec_forward(self.pc, self.Nc, 1, cx.reshape(1, E * A, -1), d_in[None], self.hc[u])
             obs, reward, done, info = env.step(step + 1, action=None if self.continuous else action)
             for k, val in (("av", av), ("cx", cx), ("mask", mask), ("action", action), ("value", v[0, :, 0].reshape(E, A)),
                            ("reward", reward.astype(np.float64)), ("log_prob", lp.reshape(E, A)), ("done_in", self.dones[u].copy()),
@@ -80,7 +84,7 @@ class OracleRecLearner:
         self.obs[u] = obs
         for k in ("av", "cx", "mask", "action", "value", "reward", "log_prob", "done_in", "ret", "len", "term"):
             tr[k] = np.stack(tr[k], 0)
-        lv, _, _ = ro.rec_forward(self.pc, self.Oc, 1, self._cx(obs).reshape(1, E * A, -1), self.dones[u].reshape(1, E * A), self.hc[u])
+        lv, _, _ = ro.rec_forward(self.pc, self.Nc, 1, self._cx(obs).reshape(1, E * A, -1), self.dones[u].reshape(1, E * A), self.hc[u])
         tr["last_val"] = lv[0, :, 0].reshape(E, A)
         tr["adv"], tr["tgt"] = po.gae(tr["reward"], tr["value"], tr["done_in"], tr["last_val"], self.h["gamma"], self.h["lam"],
                                       last_done=self.dones[u])
@@ -107,13 +111,13 @@ class OracleRecLearner:
                         eps = tn.normal_noise(self.seed, self.ent_step, 0, nA, tn.STREAM_ENTROPY, row_offset=u * T * E * A,
                                               gid=gid).astype(np.float64).reshape(T, Em * A, nA)
                         _, la, ent, g1 = ro.rec_actor_loss_grad_continuous(
-                            self.pa, self.Oa, nA, sel(tr["av"]), sel(tr["done_in"]), h0a, sel(tr["action"]), sel(tr["log_prob"]),
+                            self.pa, self.Na, nA, sel(tr["av"]), sel(tr["done_in"]), h0a, sel(tr["action"]), sel(tr["log_prob"]),
                             sel(tr["adv"]), h["clip"], h["ent"], eps)
                     else:
-                        _, la, ent, g1 = ro.rec_actor_loss_grad(self.pa, self.Oa, nA, sel(tr["av"]), sel(tr["done_in"]), h0a,
+                        _, la, ent, g1 = ro.rec_actor_loss_grad(self.pa, self.Na, nA, sel(tr["av"]), sel(tr["done_in"]), h0a,
                                                                 sel(tr["mask"]), sel(tr["action"]), sel(tr["log_prob"]),
                                                                 sel(tr["adv"]), h["clip"], h["ent"])
-                    _, vl, g2 = ro.rec_critic_loss_grad(self.pc, self.Oc, sel(tr["cx"]), sel(tr["done_in"]), h0c, sel(tr["value"]),
+                    _, vl, g2 = ro.rec_critic_loss_grad(self.pc, self.Nc, sel(tr["cx"]), sel(tr["done_in"]), h0c, sel(tr["value"]),
                                                         sel(tr["tgt"]), h["clip"], h["vf"])
                     ga += g1
                     gc += g2

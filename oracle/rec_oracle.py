@@ -33,8 +33,56 @@ H = 128
 F32_MIN = float(np.finfo(np.float32).min)
 
 
-def rec_param_count(din: int, no: int) -> int:
+def rec_param_count(din, no: int) -> int:
+    if isinstance(din, dict):  # configurable torsos (rec_spec below)
+        return _spec_counts(din, no)[-1]
     return din * H + H + H * 3 * H + 3 * H + H * 3 * H + H + H * H + H + H * no + no
+
+
+# ---- configurable pre / post torsos (mava/networks.py:39-58 MLPTorso inside RecurrentActor / RecurrentValueNet, :269-331):
+# wherever these functions take `din`, a dict from rec_spec() selects torsos other than network/rnn.yaml's [128] relu.
+# Flat layout = mava_amd/rec_networks.py's general layout: [pre torso layers | Wi | bi | Wh | bhn | post torso layers | head].
+def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False):
+    return dict(din=int(din), pre=list(pre_sizes), post=list(post_sizes), act=activation, ln=bool(layer_norm))
+
+
+def _spec_counts(spec, no):
+    from . import generic_oracle as go
+
+    n_pre = go.param_count(go.spec_mlp(spec["din"], spec["pre"], [], spec["act"], spec["ln"]))
+    np_ = spec["pre"][-1]
+    n_gru = np_ * 3 * H + 3 * H + H * 3 * H + H
+    n_post = go.param_count(go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"]))
+    return n_pre, n_gru, n_post, n_pre + n_gru + n_post
+
+
+def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, done_seq: torch.Tensor, h0: torch.Tensor):
+    from . import generic_oracle as go
+
+    n_pre, n_gru, n_post, _ = _spec_counts(spec, no)
+    np_ = spec["pre"][-1]
+    pre_spec = go.spec_mlp(spec["din"], spec["pre"], [], spec["act"], spec["ln"])
+    post_spec = go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"])
+    g = flat[n_pre : n_pre + n_gru]
+    o = 0
+    Wi = g[o : o + np_ * 3 * H].reshape(np_, 3 * H); o += np_ * 3 * H
+    bi = g[o : o + 3 * H]; o += 3 * H
+    Wh = g[o : o + H * 3 * H].reshape(H, 3 * H); o += H * 3 * H
+    bhn = g[o : o + H]
+    fpost = flat[n_pre + n_gru : n_pre + n_gru + n_post]
+    h, ys, hs = h0, [], []
+    for t in range(x_seq.shape[0]):
+        hs.append(h)
+        h = torch.where(done_seq[t][:, None], torch.zeros_like(h), h)
+        xp = go.forward(flat[:n_pre], pre_spec, x_seq[t], features=True)
+        gi = xp @ Wi + bi
+        gh = h @ Wh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H : 2 * H] + gh[:, H : 2 * H])
+        n = torch.tanh(gi[:, 2 * H :] + r * (gh[:, 2 * H :] + bhn))
+        h = (1.0 - z) * n + z * h
+        ys.append(go.forward(fpost, post_spec, h)[0])
+    return torch.stack(ys), torch.stack(hs), h
 
 
 SEGMENTS = ("Wpre", "bpre", "Wi", "bi", "Wh", "bhn", "Wpost", "bpost", "Whead", "bhead")
@@ -83,6 +131,11 @@ def gru_step(p, x, h):
 def rec_forward(flat, din, no, x_seq, done_seq, h0):
     """x_seq (T, R, din), done_seq (T, R) bool (flag entering each step), h0 (R, 128).
     Returns (outputs (T, R, no), hidden states entering each step (T, R, 128), final hidden (R, 128))."""
+    if isinstance(din, dict):
+        with torch.no_grad():
+            tt = lambda a, dt=torch.float64: torch.tensor(np.asarray(a), dtype=dt)
+            y, hs_, h_ = _t_generic_forward(tt(flat), din, no, tt(x_seq), tt(done_seq, torch.bool), tt(h0))
+        return y.numpy(), hs_.numpy(), h_.numpy()
     p = rec_unflatten(np.asarray(flat, np.float64), din, no)
     h = np.asarray(h0, np.float64)
     ys, hs = [], []
@@ -97,7 +150,10 @@ def rec_forward(flat, din, no, x_seq, done_seq, h0):
 
 
 # ------------------------------------------------------------------------------ torch (autograd) side
-def t_rec_forward(flat: torch.Tensor, din: int, no: int, x_seq: torch.Tensor, done_seq: torch.Tensor, h0: torch.Tensor):
+def t_rec_forward(flat: torch.Tensor, din, no: int, x_seq: torch.Tensor, done_seq: torch.Tensor, h0: torch.Tensor):
+    if isinstance(din, dict):
+        y, _, h = _t_generic_forward(flat, din, no, x_seq, done_seq, h0)
+        return y, h
     p = rec_unflatten(flat, din, no)
     h = h0
     ys = []

@@ -506,3 +506,75 @@ def test_fused_rec_step_matches_oracle(dev, E, A, din, S, nA, share):
     z = np.where(mask, ya[0], np.finfo(np.float32).min)
     lsm = z - np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)) - z.max(-1, keepdims=True)
     assert_close(logp.cpu().numpy()[:R], lsm[np.arange(R), a], 1e-5, "log_prob")
+
+
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
+@pytest.mark.parametrize("system,pre,post,act,ln", [("rec_mappo", [64, 96], [64], "tanh", True), ("rec_ippo", [128], [96, 32], "relu", False)])
+def test_rec_learner_general_torsos(dev, system, pre, post, act, ln, matmul):
+    """Recurrent systems with pre / post torsos other than network/rnn.yaml's [128] relu (mava/networks.py:39-58 inside
+    RecurrentActor / RecurrentValueNet): the general layer kernels around the same GRU scans, whole updates against the
+    oracle with the same torsos (oracle/rec_oracle.py rec_spec)."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_ippo, rec_mappo
+    from oracle.rec_loop import OracleRecLearner
+
+    E, U, A, O, nA, T, K, M = 16, 1, 4, 10, 5, 6, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}"])
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": nA}
+    cfg.env.kwargs.time_limit = 4
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    cfg.system.matmul_mode = matmul
+    for nc in (cfg.network.actor_network, cfg.network.critic_network):
+        nc.pre_torso.layer_sizes, nc.post_torso.layer_sizes = pre, post
+        for t in (nc.pre_torso, nc.post_torso):
+            t.activation, t.use_layer_norm = act, ln
+    central = system == "rec_mappo"
+    mod = rec_mappo if central else rec_ippo
+    env, _ = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    Oc = A * O if central else A + O
+    spec_a, spec_c = ro.rec_spec(A + O, pre, post, act, ln), ro.rec_spec(Oc, pre, post, act, ln)
+    assert L.generic_nets and not L.fused_out
+    assert L.Pa == ro.rec_param_count(spec_a, nA) and L.Pc == ro.rec_param_count(spec_c, 1)
+    tree = state.params.actor_params["params"]
+    assert tree["pre_torso"]["Dense_0"]["kernel"].shape == (1, U, A + O, pre[0])
+    assert tree["ScannedRNN_0"]["GRUCell_0"]["ir"]["kernel"].shape == (1, U, pre[-1], 128)
+    assert ("LayerNorm_0" in tree["post_torso"]) == ln
+    assert torch.equal(actor_network.flat_from_tree(state.params.actor_params), L.p[: L.Pa])
+
+    # (relu has a kink: with parameter seed 2 one post-torso pre-activation of the second update is 1.2e-7 in f32 / f64 and
+    # -3e-8 in f16x2, which moves that unit's whole gradient column; the seed below keeps every pre-activation clear of 0)
+    rng = np.random.default_rng(3 if act == "relu" else 2)
+    fa = (rng.standard_normal(L.Pa) * 0.1).astype(np.float32)
+    fc = (rng.standard_normal(L.Pc) * 0.1).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleRecLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=U, centralised=central, seed=42, actor_lr=1e-3, critic_lr=2e-3,
+                           time_limit=4, actor_net=spec_a, critic_net=spec_c)
+    ora.set_params(fa, fc)
+    ftol = 1e-5 if matmul == "f32" else 5e-5
+    for n in range(2):
+        perms = [rng.permutation(E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        rep, tr = L.reps[0], ora.last_traj[0]
+        assert np.array_equal(rep.action.cpu().numpy(), tr["action"]), "sampled actions differ"
+        assert tr["done_in"].any()
+        assert_close(rep.value.cpu().numpy(), tr["value"], ftol, "values")
+        assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], ftol, "log_probs")
+        assert_close(rep.adv.cpu().numpy(), tr["adv"], ftol, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        if matmul == "f32":
+            assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+            assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        else:
+            check_and_sync_f16x2_state(L, ora)
+    out = learn(L.learner_state())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()

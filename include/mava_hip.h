@@ -36,6 +36,11 @@ int mava_gae_f32(const float* reward, const float* value, const uint8_t* done,
                  const float* last_val, const uint8_t* last_done, int T, int N, float gamma,
                  float lambda, float* adv, float* tgt, mava_stream_t s);
 int mava_gae_set_variant(int variant); /* bench-only tuning knob, 0 = default */
+
+/* ---- epoch permutation: jax.random.permutation(key, batch_size) of ff_mappo.py:272-273 / rec_mappo.py:277-279.
+ * out[0..n) = a bijection of [0, n) determined by (seed, counter): 16-round keyed Feistel network over [0, 2^ceil(log2 n))
+ * with cycle walking (mava_amd/csrc/permutation.hip; bit-exact restatement oracle/permutation.py).  1 <= n < 2^31. */
+int mava_permutation_i32(long n, uint64_t seed, uint64_t counter, int32_t* out, mava_stream_t s);
 int mava_policy_set_variant(int variant); /* 0 = per-wave acting kernel (default), 2 = block-cooperative kernels */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam(eps=1e-5)) per network,

@@ -34,6 +34,7 @@ lng = C.c_long
 _SIGNATURES = {
     "mava_abi_version": [],
     "mava_gae_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
+    "mava_permutation_i32": [lng, u64, u64, vp, vp],
     "mava_gae_set_variant": [i32],
     "mava_ppo_set_critic_aggregation": [i32],
     "mava_ppo_set_matmul_mode": [i32],

@@ -18,6 +18,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = [
     "gae.hip",
+    "permutation.hip",
     "adam.hip",
     "mlp_policy.hip",
     "mlp_coop.hip",

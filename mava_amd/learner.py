@@ -163,7 +163,7 @@ class FFLearner:
         self.slab_c = torch.zeros((self.n_slab, self.Pc + 2), device=d)
         self.stats = torch.zeros((ops.lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
-        self.perm_gen = torch.Generator(device=d)
+        self.perm_count = 0  # epoch permutations drawn so far (counter of mava_permutation_i32)
         self.t_global = 0  # env steps taken per env so far (Philox step counter)
         self.ent_step = 0  # minibatches trained so far: counter of the continuous head's entropy sample
         # the same counter on the device: the kernels add it to their relative step, so a rollout captured in a HIP
@@ -218,7 +218,7 @@ class FFLearner:
         self.t_global = 0
         self.ent_step = 0
         self.step_dev.zero_()
-        self.perm_gen.manual_seed(self.seed)
+        self.perm_count = 0
 
     # ---------------------------------------------------------------------------- state <-> views
     def _params_tree(self) -> Params:
@@ -529,33 +529,22 @@ class FFLearner:
                       ent_coef=float(s.ent_coef), metrics_out=self.train_metrics[n, k, mb])
         self.ent_step += 1
 
-    def _permutations_async(self) -> List[torch.Tensor]:
+    def _permutations(self) -> List[torch.Tensor]:
         """ff_mappo.py:272-273: one permutation of the T*E rows per epoch, identical on every replica and rank (the
-        reference hands the same PRNG key to all of them, :417-426).  The K permutations of this update are generated on a side stream WHILE the rollout runs (they depend on
-        nothing but the generator; the sort kernels behind torch.randperm are ~0.7 ms per update on the main stream
-        at T*E = 524 288).  Written into persistent buffers, so no allocation crosses streams."""
-        main = torch.cuda.current_stream(self.device)
-        if not hasattr(self, "_perm_stream"):
-            self._perm_stream = torch.cuda.Stream(device=self.device)
+        reference hands the same PRNG key to all of them, :417-426): mava_permutation_i32 keyed by (seed, a running
+        epoch counter) - one 5 us launch each, where torch.randperm's sort passes were ~1 ms of device time per update
+        at T*E = 524 288.  Written into persistent buffers (read by the kernels of this update only)."""
+        if not hasattr(self, "_perm_bufs"):
             self._perm_bufs = [torch.empty(self.T * self.E, dtype=torch.int32, device=self.device) for _ in range(self.K)]
-            self._perm_done = torch.cuda.Event()
-        side = self._perm_stream
-        side.wait_stream(main)  # the previous update's kernels have finished reading the buffers
-        with torch.cuda.stream(side):
-            for buf in self._perm_bufs:
-                buf.copy_(torch.randperm(self.T * self.E, generator=self.perm_gen, device=self.device))
-            self._perm_done.record(side)
+        for buf in self._perm_bufs:
+            ops.permutation(self.T * self.E, self.seed, self.perm_count, out=buf)
+            self.perm_count += 1
         return self._perm_bufs
 
     def update(self, n: int, permutations: Optional[List[torch.Tensor]] = None) -> None:
         if permutations is None:
-            permutations = self._permutations_async()
-            wait_perm = True
-        else:
-            wait_perm = False
+            permutations = self._permutations()
         self._rollout(n)
-        if wait_perm:
-            torch.cuda.current_stream(self.device).wait_event(self._perm_done)
         for k in range(self.K):
             perm = permutations[k]
             for mb in range(self.M):

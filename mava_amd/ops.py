@@ -31,6 +31,16 @@ def _as_u8(t: torch.Tensor) -> torch.Tensor:
     return t.view(torch.uint8) if t.dtype == torch.bool else t
 
 
+def permutation(n: int, seed: int, counter: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 permutation of range(n) determined by (seed, counter): the epoch shuffle that stands where the reference
+    calls jax.random.permutation (ff_mappo.py:272-273); see mava_permutation_i32."""
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    _req(out, torch.int32, "out", (n,))
+    check(lib().mava_permutation_i32(n, seed & (2**64 - 1), counter & (2**64 - 1), ptr(out), stream_ptr()), "mava_permutation_i32")
+    return out
+
+
 def gae(reward, value, done, last_val, gamma: float, gae_lambda: float, last_done=None, out=None):
     """(advantages, targets) for time-major (T, ...) inputs; see mava_gae_f32."""
     T = reward.shape[0]

@@ -170,7 +170,7 @@ class RecLearner:
         self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
-        self.perm_gen = torch.Generator(device=d)
+        self.perm_count = 0  # epoch permutations drawn so far (counter of mava_permutation_i32)
         self.t_global = 0
         self.ent_step = 0  # minibatches trained so far: counter of the continuous head's entropy sample
         self.dscale_partials = torch.zeros((self.ws.loss_partials.shape[0], max(self.nA, 1)), device=d)
@@ -193,7 +193,7 @@ class RecLearner:
             rep.h_critic.zero_()
         self.t_global = 0
         self.ent_step = 0
-        self.perm_gen.manual_seed(self.seed)
+        self.perm_count = 0
 
     # ---------------------------------------------------------------------------- state views
     def learner_state(self) -> RNNLearnerState:
@@ -412,8 +412,11 @@ class RecLearner:
         self._rollout(n)
         self._bootstrap_and_gae()
         for k in range(self.K):
-            perm = (permutations[k] if permutations is not None
-                    else torch.randperm(self.E, generator=self.perm_gen, device=self.device).to(torch.int32))
+            if permutations is not None:
+                perm = permutations[k]
+            else:  # rec_mappo.py:277-279: a permutation of the env axis per epoch
+                perm = ops.permutation(self.E, self.seed, self.perm_count)
+                self.perm_count += 1
             for mb in range(self.M):
                 self._minibatch(n, k, mb, perm)
         for rep in self.reps:

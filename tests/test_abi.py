@@ -59,3 +59,11 @@ def test_comm_abi_argument_errors():
     assert lib.mava_comm_create(C.byref(h), 3, 2, idb) <= -1000 and b"rank 3 of 2" in lib.mava_last_error()
     assert lib.mava_allreduce_sum_f32(None, None, 4, None) <= -1000
     assert lib.mava_comm_destroy(None) == 0
+
+
+def test_permutation_abi_argument_errors():
+    """mava_permutation_i32: range and pointer checks come before the launch."""
+    lib = _lib.lib()
+    assert lib.mava_permutation_i32(0, 1, 0, None, None) <= -1000 and b"n=0" in lib.mava_last_error()
+    assert lib.mava_permutation_i32(1 << 31, 1, 0, None, None) <= -1000
+    assert lib.mava_permutation_i32(8, 1, 0, None, None) <= -1000 and b"null pointer" in lib.mava_last_error()

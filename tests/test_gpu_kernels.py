@@ -68,6 +68,24 @@ def test_gae_empty(dev):
     assert adv.shape == (0, 16)
 
 
+# ---------------------------------------------------------------------------------- permutation
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 64, 255, 256, 257, 1000, 4096, 4097, 65537, 524288, 1048576 + 3])
+def test_permutation_matches_oracle_bit_for_bit(dev, n):
+    """mava_permutation_i32 (the epoch shuffle, ff_mappo.py:272-273) against oracle/permutation.py: integer work, exact;
+    and a bijection of [0, n) at every size, including the non-powers of two that need the cycle walk."""
+    from mava_amd import ops
+    from oracle.permutation import permutation
+
+    for seed, counter in ((42, 0), (42, 7), (2**63 + 11, 2**40 + 5)):
+        got = ops.permutation(n, seed, counter).cpu().numpy()
+        assert got.dtype == np.int32 and np.array_equal(got, permutation(n, seed, counter))
+        assert np.array_equal(np.sort(got), np.arange(n))
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    assert ops.permutation(n, 42, 7, out=out) is out
+    with pytest.raises(ValueError):
+        ops.permutation(n, 42, 7, out=torch.empty(n + 1, dtype=torch.int32, device=dev))
+
+
 # ----------------------------------------------------------------------------------------- Adam
 @pytest.mark.parametrize("decay", [False, True])
 @pytest.mark.parametrize("big_grad", [False, True])

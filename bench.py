@@ -269,7 +269,7 @@ def main() -> None:
     # run - it is attached from the committed rocprofv3 PMC pass of the same workload named in `traffic_source`
     # (regenerated per round with tools/pmc_traffic.sh; stale once a kernel changes after that pass).
     traffic, traffic_source = {}, None
-    for name in ("r02_v2_pmc_traffic.json", "r02_v1_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
+    for name in ("r02_v3_pmc_traffic.json", "r02_v2_pmc_traffic.json", "r02_v1_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["kernels"]
@@ -409,7 +409,7 @@ def main() -> None:
         hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tf / mfma_peak
         rec_traffic, rec_src = None, None
         kname = f"{dom}_h2_kernel" if args.matmul == "f16x2" else f"{dom}_kernel"
-        for fname in ("r02_rec2_pmc_traffic.json", "r02_rec_pmc_traffic.json", "r01_rec_v5_pmc.json"):
+        for fname in ("r02_rec3_pmc_traffic.json", "r02_rec2_pmc_traffic.json", "r02_rec_pmc_traffic.json", "r01_rec_v5_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     rec_traffic = (json.load(f).get("kernels", {}).get(f"{kname} grid={min(256, seqs // 32)}", {})

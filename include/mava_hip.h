@@ -112,6 +112,10 @@ int mava_adv_stats_blocks(void); /* number of (sum, sumsq) f64 pairs mava_adv_st
 /* advantage statistics for ff_mappo.py:164 (mean / population std over the whole minibatch) */
 int mava_adv_stats_f64(const float* advantages, const int32_t* idx, long idx_base, int Rb, int A,
                        double* partials, mava_stream_t s);
+/* the same for n_batch minibatches in one launch: minibatch j uses idx[j * idx_stride ...) and writes
+ * partials[j][mava_adv_stats_blocks()][2] (all epochs x minibatches of an update, once GAE has run) */
+int mava_adv_stats_batched_f64(const float* advantages, const int32_t* idx, long idx_stride, int Rb, int A,
+                               int n_batch, double* partials, mava_stream_t s);
 
 /* _actor_loss_fn, ff_mappo.py:150-180.  slab tail: [actor_loss, entropy]. */
 int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const float* agents_view,

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "mava_rec_xty_set_variant": [i32],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
+    "mava_adv_stats_batched_f64": [vp, vp, lng, i32, i32, i32, vp, vp],
     "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
     "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],

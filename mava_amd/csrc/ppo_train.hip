@@ -86,8 +86,11 @@ TrainLdsLayout make_layout(int kt1) {
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv,
                                                         const int32_t* __restrict__ idx,
                                                         long idx_base, int Rb, int A,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials, long idx_stride) {
   __shared__ double sh[2][4];
+  // blockIdx.y = minibatch of a batched launch (mava_adv_stats_batched_f64): its index slice and its partials
+  if (idx) idx += (long)blockIdx.y * idx_stride;
+  partials += (long)blockIdx.y * 2 * gridDim.x;
   double s1 = 0.0, s2 = 0.0;
   const long stride = (long)gridDim.x * 256;
   for (long b0 = (long)blockIdx.x * 256 + threadIdx.x; b0 < Rb; b0 += 4 * stride) {
@@ -1033,7 +1036,21 @@ extern "C" int mava_adv_stats_f64(const float* adv, const int32_t* idx, long idx
   MAVA_ARG_CHECK(Rb >= 1 && A >= 1, 0, "mava_adv_stats_f64: Rb=%d A=%d", Rb, A);
   MAVA_ARG_CHECK(adv && partials, 1, "mava_adv_stats_f64: null pointer argument");
   hipLaunchKernelGGL(adv_stats_kernel, dim3(STATS_BLOCKS), dim3(256), 0, s, adv, idx, idx_base, Rb, A,
-                     partials);
+                     partials, 0L);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+// The statistics of n_batch minibatches in one launch: minibatch j takes the indices idx[j * idx_stride ...) and writes
+// partials[j][mava_adv_stats_blocks()][2] - e.g. all ppo_epochs x num_minibatches slices of an update's permutations,
+// known as soon as GAE has run (each 15 us launch on the critical path otherwise).
+extern "C" int mava_adv_stats_batched_f64(const float* adv, const int32_t* idx, long idx_stride, int Rb, int A,
+                                          int n_batch, double* partials, hipStream_t s) {
+  MAVA_ARG_CHECK(Rb >= 1 && A >= 1 && n_batch >= 1 && n_batch <= 65535 && idx_stride >= 0, 0,
+                 "mava_adv_stats_batched_f64: Rb=%d A=%d n_batch=%d idx_stride=%ld", Rb, A, n_batch, idx_stride);
+  MAVA_ARG_CHECK(adv && idx && partials, 1, "mava_adv_stats_batched_f64: null pointer argument");
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(STATS_BLOCKS, n_batch), dim3(256), 0, s, adv, idx, 0L, Rb, A, partials,
+                     idx_stride);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

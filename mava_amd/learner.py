@@ -408,15 +408,18 @@ class FFLearner:
         # actor: gradient kernels of every replica, fixed-order slab sum into g[:Pa] (+ actor_loss, entropy)
         for u, rep in enumerate(self.reps):
             av = rep.agents_view[:T].view(TEA, self.Oa)
-            ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
+            if getattr(self, "_stats_batched", False) and perm is self._perm_bufs[k]:
+                stats = self._stats_all[u, k * self.M + mb]
+            else:
+                stats = ops.adv_stats(rep.adv.view(TEA), idx, base, self.Rb, A, out=self.stats)
             if self.continuous:
                 self._timed("actor_grad", ops.ppo_actor_grad_continuous, pa, av, rep.action.view(TEA, self.nA),
-                            rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base, self.Rb, A, self.nA,
+                            rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base, self.Rb, A, self.nA,
                             float(s.clip_eps), float(s.ent_coef), self.seed, self.ent_step,
                             (self.rank * self.U + u) * TEA, self.slab_a)
             else:
                 self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
-                            rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), self.stats, idx, base,
+                            rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base,
                             self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a)
             ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
         # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
@@ -535,16 +538,26 @@ class FFLearner:
         epoch counter) - one 5 us launch each, where torch.randperm's sort passes were ~1 ms of device time per update
         at T*E = 524 288.  Written into persistent buffers (read by the kernels of this update only)."""
         if not hasattr(self, "_perm_bufs"):
-            self._perm_bufs = [torch.empty(self.T * self.E, dtype=torch.int32, device=self.device) for _ in range(self.K)]
+            self._perm_all = torch.empty((self.K, self.T * self.E), dtype=torch.int32, device=self.device)
+            self._perm_bufs = [self._perm_all[k] for k in range(self.K)]
+            self._stats_all = torch.empty((self.U, self.K * self.M, self.stats.shape[0], 2), dtype=torch.float64, device=self.device)
         for buf in self._perm_bufs:
             ops.permutation(self.T * self.E, self.seed, self.perm_count, out=buf)
             self.perm_count += 1
         return self._perm_bufs
 
     def update(self, n: int, permutations: Optional[List[torch.Tensor]] = None) -> None:
-        if permutations is None:
+        own = permutations is None
+        if own:
             permutations = self._permutations()
         self._rollout(n)
+        # advantage statistics of ALL K x M minibatches in one launch per replica (the permutations are this learner's
+        # own contiguous buffer: minibatch (k, mb) = slice k * M + mb of it); otherwise one launch per minibatch
+        self._stats_batched = own and not self.generic
+        if self._stats_batched:
+            for u, rep in enumerate(self.reps):
+                ops.adv_stats_batched(rep.adv.view(-1), self._perm_all.view(-1), self.Rb, self.A, self.K * self.M,
+                                      out=self._stats_all[u])
         for k in range(self.K):
             perm = permutations[k]
             for mb in range(self.M):

@@ -286,6 +286,22 @@ def ppo_actor_grad_continuous(params, agents_view, action, old_log_prob, advanta
     )
 
 
+def adv_stats_batched(advantages: torch.Tensor, idx: torch.Tensor, Rb: int, A: int, n_batch: int,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """adv_stats of n_batch consecutive Rb-slices of idx in one launch: out[j] = the partials of idx[j*Rb : (j+1)*Rb]."""
+    _req(advantages, torch.float32, "advantages")
+    _req(idx, torch.int32, "idx")
+    if idx.numel() < n_batch * Rb:
+        raise ValueError("idx shorter than n_batch * Rb")
+    nb = lib().mava_adv_stats_blocks()
+    if out is None:
+        out = torch.empty((n_batch, nb, 2), dtype=torch.float64, device=advantages.device)
+    _req(out, torch.float64, "out", (n_batch, nb, 2))
+    check(lib().mava_adv_stats_batched_f64(ptr(advantages), ptr(idx), Rb, Rb, A, n_batch, ptr(out), stream_ptr()),
+          "mava_adv_stats_batched_f64")
+    return out
+
+
 def adv_stats(advantages: torch.Tensor, idx: Optional[torch.Tensor], idx_base: int, Rb: int, A: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """f64 (sum, sumsq) partials of the minibatch advantages, consumed by ppo_actor_grad."""

@@ -86,6 +86,29 @@ def test_permutation_matches_oracle_bit_for_bit(dev, n):
         ops.permutation(n, 42, 7, out=torch.empty(n + 1, dtype=torch.int32, device=dev))
 
 
+def test_adv_stats_batched_equals_per_minibatch(dev):
+    """mava_adv_stats_batched_f64 (all epochs x minibatches of an update in one launch) = the per-minibatch launches bit
+    for bit, and their sums give the float64 mean / variance of the gathered advantages (ff_mappo.py:164)."""
+    from mava_amd import ops
+
+    rng = np.random.default_rng(3)
+    TE, A, K, M = 4096, 3, 2, 4
+    Rb = TE // M
+    adv = rng.standard_normal((TE, A)).astype(np.float32)
+    perms = np.stack([rng.permutation(TE) for _ in range(K)]).astype(np.int32)
+    adv_d, perm_d = _t(adv, dev), _t(perms, dev)
+    got = ops.adv_stats_batched(adv_d.view(-1), perm_d.view(-1), Rb, A, K * M)
+    for k in range(K):
+        for mb in range(M):
+            one = ops.adv_stats(adv_d.view(-1), perm_d[k, mb * Rb : (mb + 1) * Rb].contiguous(), 0, Rb, A)
+            assert torch.equal(got[k * M + mb], one)
+            sel = adv[perms[k, mb * Rb : (mb + 1) * Rb]].astype(np.float64)
+            s1, s2 = got[k * M + mb].sum(0).cpu().numpy()
+            np.testing.assert_allclose([s1, s2], [sel.sum(), (sel * sel).sum()], rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        ops.adv_stats_batched(adv_d.view(-1), perm_d.view(-1), Rb, A, K * M + 1)
+
+
 # ----------------------------------------------------------------------------------------- Adam
 @pytest.mark.parametrize("decay", [False, True])
 @pytest.mark.parametrize("big_grad", [False, True])

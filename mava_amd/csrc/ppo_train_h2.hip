@@ -112,6 +112,16 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   static_assert(!WIDE || S1 % W1_RING == 0, "WIDE: S1 must be a multiple of the W1 ring depth");
   static_assert((ROLE == 0) == !WIDE, "roles 1 / 2 belong to WIDE launches");
   constexpr bool CHAIN = ROLE != 2, LOADER = ROLE != 1;
+#if defined(MAVA_NO_W2_RESIDENT) || defined(MAVA_W2_RESIDENT_P4)
+  constexpr bool W2_RESIDENT = false;
+#else
+  constexpr bool W2_RESIDENT = !WIDE && ACTOR && NO <= 16;
+#endif
+#ifdef MAVA_W2_RESIDENT_P4
+  constexpr bool W2_RES4 = !WIDE && ACTOR && NO <= 16;
+#else
+  constexpr bool W2_RES4 = false;
+#endif
   constexpr int NTHR = WIDE ? 512 : 256;
   constexpr int KT1 = (S1 + 1) / 2;  // 32-input tiles of the layer-1 weight gradient
   u8* const H1I = lds + L.h1;
@@ -407,6 +417,17 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
   const int w2row = (32 * w + r) * IMG_ROW + 16 * h;           // + 32 s: W2[32w + r][16s + 8h .. + 7]
   int buf = 0;
+  // narrow inputs: this wave's layer-2 operand (its 32 columns of W2, all 8 steps: 64 registers of the ~110 the role
+  // leaves free) stays in registers - P2 then reads only the h1 image, half the LDS bytes of the phase
+  Frag w2r[(W2_RESIDENT || W2_RES4) ? 8 : 1];
+  if constexpr (W2_RESIDENT) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w2r[s] = read_tr_frag(W2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
+  }
+  if constexpr (W2_RES4) {  // (measured alternative: the backward operand W2[32w + r][.] instead)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w2r[s] = read_row_frag(W2I, W2_PLANE, w2row + 32 * s);
+  }
 
   STAMP_DECL
   for (; it < ntiles; it += gridDim.x, buf ^= (WIDE ? 0 : 1)) {
@@ -490,13 +511,14 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll
     for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
     {
-      Frag an = read_tr_frag(W2I + trI + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
+      Frag an;
+      if constexpr (!W2_RESIDENT) an = read_tr_frag(W2I + trI + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
       Frag bn = read_row_frag(H1I, IMG_PLANE, rowB);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const Frag a = an, b = bn;
+        const Frag a = W2_RESIDENT ? w2r[s] : an, b = bn;
         if (s + 1 < 8) {
-          an = read_tr_frag(W2I + trI + 16 * (s + 1) * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
+          if constexpr (!W2_RESIDENT) an = read_tr_frag(W2I + trI + 16 * (s + 1) * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
           bn = read_row_frag(H1I, IMG_PLANE, rowB + 32 * (s + 1));
         }
         h2 = mfma3(a, b, h2);
@@ -683,13 +705,14 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if constexpr (CHAIN) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-      Frag an = read_row_frag(W2I, W2_PLANE, w2row);
+      Frag an;
+      if constexpr (!W2_RES4) an = read_row_frag(W2I, W2_PLANE, w2row);
       Frag bn = read_row_frag(DZ2I, IMG_PLANE, rowB);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const Frag a = an, b = bn;
+        const Frag a = W2_RES4 ? w2r[s] : an, b = bn;
         if (s + 1 < 8) {
-          an = read_row_frag(W2I, W2_PLANE, w2row + 32 * (s + 1));
+          if constexpr (!W2_RES4) an = read_row_frag(W2I, W2_PLANE, w2row + 32 * (s + 1));
           bn = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * (s + 1));
         }
         acc = mfma3(a, b, acc);

@@ -113,6 +113,80 @@ __device__ __forceinline__ void write_image(u8* img, int r, int col0 /* 32w + 4h
 }
 
 
+// ---- Swizzled images: [rows][128 features] f16 in 256-byte rows, 16-byte chunk c of row `row` stored at chunk
+// c ^ sw(row), sw(row) = ((row & 3) << 2) | ((row >> 2) & 3).  The padded images above (272-byte rows) serve row reads
+// without conflicts, but the four block rows a transposed read's 32-lane half touches land 4 banks apart there: every
+// ds_read_b64_tr_b16 is 4-way conflicted (8 LDS cycles instead of 2).  With the XOR both kinds of read are conflict-free
+// (bank = (a / 4) % 64 for ds_read_b128 / _b64_tr_b16; lane groups as in MI355X_MICROARCH.md, LDS).  Rows are addressed
+// modulo 16 by sw, so an image may have any multiple of 16 rows (W2: 128).
+constexpr int SW_ROW = 256;
+constexpr int SW_PLANE = 32 * SW_ROW;
+__device__ __forceinline__ int sw_of(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int sw_off(int row, int chunk) { return SW_ROW * row + 16 * (chunk ^ sw_of(row)); }
+// row read by lane (r, h): features 16 s + 8 h .. + 7 (chunk 2 s + h) of image row `row`
+struct SwRow {
+  int base, hx;
+};
+__device__ __forceinline__ SwRow sw_row(int row, int h) {
+  SwRow a;
+  a.base = SW_ROW * row;
+  a.hx = (16 * h) ^ (16 * sw_of(row));
+  return a;
+}
+__device__ __forceinline__ Frag sw_read_row(const u8* img, int plane_bytes, const SwRow& a, int s) {
+  return read_row_frag(img, plane_bytes, a.base + ((32 * s) ^ a.hx));
+}
+// transposed read: rows 16 s + 8 h + 0..7 of column tile t (columns 32 t + r).  Lane 4q + p of a 16-lane group supplies
+// row q (second read: q + 4) of the block, chunk 4 t + 2 g1 + (p >> 1), byte 8 (p & 1) of it.
+struct SwTr {
+  int b0, b1, q64;
+};
+__device__ __forceinline__ SwTr sw_tr(int lane) {
+  const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
+  const int cx = 2 * g1 + (p >> 1);
+  const int trb = SW_ROW * (8 * h + q) + 8 * (p & 1);
+  SwTr a;
+  a.b0 = trb + 16 * (cx ^ (2 * h));                    // rows 8h + q:     (row >> 2) & 3 = 2h
+  a.b1 = trb + 16 * (cx ^ (2 * h + 1)) + 4 * SW_ROW;   // rows 8h + 4 + q: (row >> 2) & 3 = 2h + 1
+  a.q64 = 64 * q;
+  return a;
+}
+__device__ __forceinline__ Frag sw_read_tr(const u8* img, int plane_bytes, const SwTr& a, int s, int t) {
+  const int x = ((64 * t) ^ a.q64) + 16 * s * SW_ROW;
+  const u8* p0 = img + a.b0 + x;
+  const u8* p1 = img + a.b1 + x;
+  Frag f;
+  {
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p0));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p1));
+    f.hi = __builtin_bit_cast(half8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+  {
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p0 + plane_bytes));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p1 + plane_bytes));
+    f.lo = __builtin_bit_cast(half8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+  return f;
+}
+// write_image for a swizzled image: the wave's features 32 w + 4 h + 8 g .. + 3 of row r = chunk 4 w + g, byte 8 h
+__device__ __forceinline__ void sw_write_image(u8* img, int r, int w, int h, const f32x16& acc, half4 (&ph)[4],
+                                               half4 (&pl)[4]) {
+  const int sw16 = 16 * sw_of(r);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a, b;
+      split1(acc[4 * g + e], a, b);
+      ph[g][e] = a;
+      pl[g][e] = b;
+    }
+    u8* p = img + SW_ROW * r + 8 * h + ((64 * w + 16 * g) ^ sw16);
+    *reinterpret_cast<half4*>(p) = ph[g];
+    *reinterpret_cast<half4*>(p + SW_PLANE) = pl[g];
+  }
+}
+
 // All-reduce over aligned groups of G consecutive lanes (G = 8, 16, 32) on the VALU's DPP path (as ppo_train.hip)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

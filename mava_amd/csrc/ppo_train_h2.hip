@@ -76,7 +76,7 @@ H2Layout make_h2_layout(bool actor) {
   L.end = L.small + (128 + 32 + 16 + 128) * 4;
   return L;
 }
-constexpr int W2_PLANE = 128 * IMG_ROW;
+constexpr int W2_PLANE = 128 * SW_ROW;  // (the images of this kernel are the swizzled ones of h2_core.h; regions keep IMG_BYTES)
 constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 is padded to a multiple of it)
 
 // WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
@@ -170,8 +170,9 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       for (int k = k0; k < k0 + 64; ++k) {
         _Float16 x0, x1;
         split1_carry(P[oW2 + k * MLP_H + n], carry, x0, x1);
-        *reinterpret_cast<_Float16*>(W2I + k * IMG_ROW + 2 * n) = x0;
-        *reinterpret_cast<_Float16*>(W2I + W2_PLANE + k * IMG_ROW + 2 * n) = x1;
+        const int o = sw_off(k, n >> 3) + 2 * (n & 7);
+        *reinterpret_cast<_Float16*>(W2I + o) = x0;
+        *reinterpret_cast<_Float16*>(W2I + W2_PLANE + o) = x1;
       }
     }
     if (ACTOR && tid == 0) {
@@ -409,24 +410,24 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   __syncthreads();
 
   // per-lane LDS byte offsets
-  const int rowB = r * IMG_ROW + 16 * h;                       // + 32 s: features 16s + 8h .. + 7 of image row r
+  const SwRow rowB = sw_row(r, h);                             // step s: features 16s + 8h .. + 7 of image row r
+  const SwTr trS = sw_tr(lane);                                // transposed reads of the swizzled images
   const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, g1 = (lane >> 4) & 1;
   // transposed reads: block row (8h + tq) of a 16-row step, columns (16 g1 + 4 tp) .. + 3 of a 32-column tile
-  const int trI = (8 * h + tq) * IMG_ROW + 2 * (16 * g1 + 4 * tp);  // + 16 s * IMG_ROW + 2 * (first column of the tile)
   const int trX = (8 * h + tq) * xs_row + 2 * (16 * g1 + 4 * tp);
   const int trD = (8 * h + tq) * DY_ROW + 2 * (16 * g1 + 4 * tp);
-  const int w2row = (32 * w + r) * IMG_ROW + 16 * h;           // + 32 s: W2[32w + r][16s + 8h .. + 7]
+  const SwRow w2row = sw_row(32 * w + r, h);                   // step s: W2[32w + r][16s + 8h .. + 7]
   int buf = 0;
   // narrow inputs: this wave's layer-2 operand (its 32 columns of W2, all 8 steps: 64 registers of the ~110 the role
   // leaves free) stays in registers - P2 then reads only the h1 image, half the LDS bytes of the phase
   Frag w2r[(W2_RESIDENT || W2_RES4) ? 8 : 1];
   if constexpr (W2_RESIDENT) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) w2r[s] = read_tr_frag(W2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
+    for (int s = 0; s < 8; ++s) w2r[s] = sw_read_tr(W2I, W2_PLANE, trS, s, w);
   }
   if constexpr (W2_RES4) {  // (measured alternative: the backward operand W2[32w + r][.] instead)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) w2r[s] = read_row_frag(W2I, W2_PLANE, w2row + 32 * s);
+    for (int s = 0; s < 8; ++s) w2r[s] = sw_read_row(W2I, W2_PLANE, w2row, s);
   }
 
   STAMP_DECL
@@ -476,7 +477,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     }
     {
       half4 ph[4], pl[4];
-      write_image(H1I, r, 32 * w + 4 * h, acc, ph, pl);
+      sw_write_image(H1I, r, w, h, acc, ph, pl);
     }
     }  // CHAIN
     STAMP(1);
@@ -512,14 +513,14 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
     {
       Frag an;
-      if constexpr (!W2_RESIDENT) an = read_tr_frag(W2I + trI + 2 * (32 * w), W2_PLANE, IMG_ROW);  // W2[16s+8h+e][32w+r]
-      Frag bn = read_row_frag(H1I, IMG_PLANE, rowB);
+      if constexpr (!W2_RESIDENT) an = sw_read_tr(W2I, W2_PLANE, trS, 0, w);  // W2[16s+8h+e][32w+r]
+      Frag bn = sw_read_row(H1I, SW_PLANE, rowB, 0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const Frag a = W2_RESIDENT ? w2r[s] : an, b = bn;
         if (s + 1 < 8) {
-          if constexpr (!W2_RESIDENT) an = read_tr_frag(W2I + trI + 16 * (s + 1) * IMG_ROW + 2 * (32 * w), W2_PLANE, IMG_ROW);
-          bn = read_row_frag(H1I, IMG_PLANE, rowB + 32 * (s + 1));
+          if constexpr (!W2_RESIDENT) an = sw_read_tr(W2I, W2_PLANE, trS, s + 1, w);
+          bn = sw_read_row(H1I, SW_PLANE, rowB, s + 1);
         }
         h2 = mfma3(a, b, h2);
         __builtin_amdgcn_sched_barrier(0);
@@ -541,7 +542,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       if (h == 0) YP[(w * 32 + r) * (NO + 1)] = part;
     } else {
       half4 ph[4], pl[4];
-      write_image(H2I, r, 32 * w + 4 * h, h2, ph, pl);
+      sw_write_image(H2I, r, w, h, h2, ph, pl);
       f32x16 yacc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) yacc[q] = 0.0f;
@@ -650,7 +651,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const Frag a = read_tr_frag(DYI + trD + 16 * s * DY_ROW, DY_PLANE, DY_ROW);
-        const Frag b = read_tr_frag(H2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+        const Frag b = sw_read_tr(H2I, SW_PLANE, trS, s, w);
         gW3 = mfma3(a, b, gW3);
       }
       // dz2^T[f][row] = sum_o W3[f][o] dy[row][o]: one 16-output step
@@ -681,7 +682,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     }
     {
       half4 ph[4], pl[4];
-      write_image(DZ2I, r, 32 * w + 4 * h, dz, ph, pl);
+      sw_write_image(DZ2I, r, w, h, dz, ph, pl);
     }
     }  // CHAIN
     STAMP(8);
@@ -693,10 +694,10 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const Frag b = read_tr_frag(DZ2I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+        const Frag b = sw_read_tr(DZ2I, SW_PLANE, trS, s, w);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const Frag a = read_tr_frag(H1I + trI + 16 * s * IMG_ROW + 2 * (32 * t), IMG_PLANE, IMG_ROW);
+          const Frag a = sw_read_tr(H1I, SW_PLANE, trS, s, t);
           gW2[t] = mfma3(a, b, gW2[t]);
           if (t & 1) __builtin_amdgcn_sched_barrier(0);  // at most two tiles' operand reads in flight
         }
@@ -706,14 +707,14 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
       Frag an;
-      if constexpr (!W2_RES4) an = read_row_frag(W2I, W2_PLANE, w2row);
-      Frag bn = read_row_frag(DZ2I, IMG_PLANE, rowB);
+      if constexpr (!W2_RES4) an = sw_read_row(W2I, W2_PLANE, w2row, 0);
+      Frag bn = sw_read_row(DZ2I, SW_PLANE, rowB, 0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const Frag a = W2_RES4 ? w2r[s] : an, b = bn;
         if (s + 1 < 8) {
-          if constexpr (!W2_RES4) an = read_row_frag(W2I, W2_PLANE, w2row + 32 * (s + 1));
-          bn = read_row_frag(DZ2I, IMG_PLANE, rowB + 32 * (s + 1));
+          if constexpr (!W2_RES4) an = sw_read_row(W2I, W2_PLANE, w2row, s + 1);
+          bn = sw_read_row(DZ2I, SW_PLANE, rowB, s + 1);
         }
         acc = mfma3(a, b, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -721,7 +722,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
       half4 ph[4], pl[4];
-      write_image(DZ1I, r, 32 * w + 4 * h, acc, ph, pl);
+      sw_write_image(DZ1I, r, w, h, acc, ph, pl);
     }
     if constexpr (!WIDE) {
       // narrow inputs: the next tile's x rows have arrived long ago - split + store them into the other buffer (read
@@ -738,7 +739,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const Frag b = read_tr_frag(DZ1I + trI + 16 * s * IMG_ROW + 2 * (32 * w), IMG_PLANE, IMG_ROW);
+        const Frag b = sw_read_tr(DZ1I, SW_PLANE, trS, s, w);
 #pragma unroll
         for (int t = 0; t < KT1; ++t) {
           const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);

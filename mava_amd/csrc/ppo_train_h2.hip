@@ -115,7 +115,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #if defined(MAVA_NO_W2_RESIDENT) || defined(MAVA_W2_RESIDENT_P4)
   constexpr bool W2_RESIDENT = false;
 #else
-  constexpr bool W2_RESIDENT = !WIDE && ACTOR && NO <= 16;
+  constexpr bool W2_RESIDENT = !WIDE && NO <= 16;
 #endif
 #ifdef MAVA_W2_RESIDENT_P4
   constexpr bool W2_RES4 = !WIDE && ACTOR && NO <= 16;

@@ -29,6 +29,18 @@
 #include "h2_core.h"
 #include "ppo_train_task.h"
 
+// Operand prefetch depth of the weight-gradient products (0 = pairs of reads followed by pairs of products).  A rolling
+// prefetch (operand of product i + depth read while product i runs) was measured at depth 3 (narrow kernels) and 2 / 3 (the
+// wide kernel's loader role): actor 5.12 vs 5.10 ms per update - nothing -, critic 2.31 / 2.43 vs 2.20 ms - the extra live
+// fragments spill in the wide roles (44 / 76 bytes of scratch per lane).  Kept selectable; off.
+#ifndef MAVA_GW_DEPTH
+#define MAVA_GW_DEPTH 0
+#endif
+#define GW_DEPTH MAVA_GW_DEPTH
+#ifndef MAVA_GW_DEPTH_WIDE
+#define MAVA_GW_DEPTH_WIDE 0
+#endif
+
 namespace {
 
 using namespace h2;
@@ -535,9 +547,17 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if (!ACTOR) {
       // critic head on the VALU: this lane's 16 features of row r, the two lane halves added by one exchange; the four
       // waves' partial values meet in YP
+      // (this lane's 16 head weights are four aligned groups of four: 16-byte reads, issued together)
+      float4 w3g[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w3g[g] = *reinterpret_cast<const float4*>(W3s + 32 * w + 4 * h + 8 * g);
       float part = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) part = fmaf(h2[q], W3s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h], part);
+      for (int q = 0; q < 16; ++q) {
+        const float4 t = w3g[q >> 2];
+        const float w3 = (q & 3) == 0 ? t.x : (q & 3) == 1 ? t.y : (q & 3) == 2 ? t.z : t.w;
+        part = fmaf(h2[q], w3, part);
+      }
       part += __shfl_xor(part, 32, 64);
       if (h == 0) YP[(w * 32 + r) * (NO + 1)] = part;
     } else {
@@ -645,6 +665,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     }  // CHAIN
     STAMP(7);
     __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
+    STAMP(15);
     if constexpr (CHAIN) {
     if (ACTOR) {
       // gW3^T[o][f = 32w + r] += sum_rows dy[row][o] h2[row][f]   (outputs >= NO of the dy image are zero)
@@ -667,15 +688,27 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
         ab2[q] += dz[q];
       }
     } else {
+      // every LDS value of this phase is loaded up front and unconditionally: written as a select per element the
+      // compiler turned each `relu ? W3s[..] * dy0 : 0` into a branch around one LDS read followed by lgkmcnt(0) -
+      // sixteen serial round trips, 3.0 K cycles per tile for this phase (phase stamps) instead of ~1 K
+      float4 w3g[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w3g[g] = *reinterpret_cast<const float4*>(W3s + 32 * w + 4 * h + 8 * g);
       if (tk.agg > 1) {
+        float av[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) av[a] = AGG[a * 33 + r];
         float sum = 0.0f;
 #pragma unroll
-        for (int a = 0; a < 8; ++a) sum += AGG[a * 33 + r];  // fixed order: identical in every lane
+        for (int a = 0; a < 8; ++a) sum += av[a];  // fixed order: identical in every lane
         dy0 = sum;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        dz[q] = ((relu2 >> q) & 1u) ? (W3s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] * dy0) : 0.0f;
+        const float4 t = w3g[q >> 2];
+        const float w3 = (q & 3) == 0 ? t.x : (q & 3) == 1 ? t.y : (q & 3) == 2 ? t.z : t.w;
+        const float v = w3 * dy0;
+        dz[q] = ((relu2 >> q) & 1u) ? v : 0.0f;
         ab2[q] += dz[q];
         aW3r[q] = fmaf(h2[q], dy0, aW3r[q]);
       }
@@ -692,14 +725,31 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     // ---------------------------------------------------------------- P4: dh1 = W2 dz2^T -> dz1 ; dW2 ; dW1
     auto do_gw2 = [&]() {
       // gW2[k][n = 32w + r] += sum_rows h1[row][k] dz2[row][n]
+      constexpr int D2 = WIDE ? 0 : GW_DEPTH;  // (the wide chain role has no registers left for a deeper prefetch: it spills)
+      if constexpr (D2 > 0) {
+        // rolling prefetch: the operand of product i + D2 is read while product i runs (pairs of reads followed by pairs
+        // of products ran at ~170 cycles per 96-cycle product: the LDS round trip was exposed once per pair)
+        const Frag b0 = sw_read_tr(DZ2I, SW_PLANE, trS, 0, w), b1 = sw_read_tr(DZ2I, SW_PLANE, trS, 1, w);
+        Frag a[D2 > 0 ? D2 : 1];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const Frag b = sw_read_tr(DZ2I, SW_PLANE, trS, s, w);
+        for (int i = 0; i < D2; ++i) a[i] = sw_read_tr(H1I, SW_PLANE, trS, i >> 2, i & 3);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const Frag a = sw_read_tr(H1I, SW_PLANE, trS, s, t);
-          gW2[t] = mfma3(a, b, gW2[t]);
-          if (t & 1) __builtin_amdgcn_sched_barrier(0);  // at most two tiles' operand reads in flight
+        for (int i = 0; i < 8; ++i) {
+          const Frag cur = a[i % (D2 > 0 ? D2 : 1)];
+          if (i + D2 < 8) a[i % (D2 > 0 ? D2 : 1)] = sw_read_tr(H1I, SW_PLANE, trS, (i + D2) >> 2, (i + D2) & 3);
+          gW2[i & 3] = mfma3(cur, (i >> 2) ? b1 : b0, gW2[i & 3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Frag b = sw_read_tr(DZ2I, SW_PLANE, trS, s, w);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const Frag a = sw_read_tr(H1I, SW_PLANE, trS, s, t);
+            gW2[t] = mfma3(a, b, gW2[t]);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);  // at most two tiles' operand reads in flight
+          }
         }
       }
     };
@@ -737,14 +787,32 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if constexpr (WIDE && CHAIN) do_gw2();  // beside the loader group's dW1 product
     if constexpr (LOADER) {
       // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
+      constexpr int NPR = 2 * KT1;                          // products
+      constexpr int D1 = WIDE ? MAVA_GW_DEPTH_WIDE : GW_DEPTH;  // operand prefetch depth (see do_gw2)
+      if constexpr (D1 > 0) {
+        constexpr int DP = D1 < NPR ? D1 : NPR;
+        const Frag b0 = sw_read_tr(DZ1I, SW_PLANE, trS, 0, w), b1 = sw_read_tr(DZ1I, SW_PLANE, trS, 1, w);
+        Frag a[DP > 0 ? DP : 1];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const Frag b = sw_read_tr(DZ1I, SW_PLANE, trS, s, w);
+        for (int i = 0; i < DP; ++i) a[i] = read_tr_frag(XSI + trX + 16 * (i / KT1) * xs_row + 2 * (32 * (i % KT1)), xs_plane, xs_row);
 #pragma unroll
-        for (int t = 0; t < KT1; ++t) {
-          const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);
-          gW1[t] = mfma3(a, b, gW1[t]);
-          if (t & 1) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NPR; ++i) {
+          const Frag cur = a[i % (DP > 0 ? DP : 1)];
+          if (i + DP < NPR)
+            a[i % (DP > 0 ? DP : 1)] = read_tr_frag(XSI + trX + 16 * ((i + DP) / KT1) * xs_row + 2 * (32 * ((i + DP) % KT1)), xs_plane, xs_row);
+          gW1[i % KT1] = mfma3(cur, (i / KT1) ? b1 : b0, gW1[i % KT1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Frag b = sw_read_tr(DZ1I, SW_PLANE, trS, s, w);
+#pragma unroll
+          for (int t = 0; t < KT1; ++t) {
+            const Frag a = read_tr_frag(XSI + trX + 16 * s * xs_row + 2 * (32 * t), xs_plane, xs_row);
+            gW1[t] = mfma3(a, b, gW1[t]);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }

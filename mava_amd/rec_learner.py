@@ -125,23 +125,29 @@ class RecLearner:
                 rep.set_critic_rows(1)
 
         net = config.network
-        from .generic_networks import GenericMLPTorso
+        from .generic_networks import CNNTorso, GenericMLPTorso
 
         def torsos(nc):
             """(pre, post) of one network: network/rnn.yaml's [128] relu torsos run on the dedicated kernels; any other
-            MLPTorso configuration (layer sizes, tanh, layer norm) makes BOTH torsos of that network general ones."""
+            configuration - MLPTorso layer sizes / tanh / layer norm, or network/rcnn.yaml's CNNTorso pre-torso - makes BOTH
+            torsos of that network general ones."""
+            is_cnn = lambda raw: str(dict(raw).get("_target_", "MLPTorso")).endswith("CNNTorso")
             cfgs = [{k: v for k, v in c.items() if k != "_target_"} for c in (nc.pre_torso, nc.post_torso)]
-            for c, raw in zip(cfgs, (nc.pre_torso, nc.post_torso)):
-                if str(dict(raw).get("_target_", "MLPTorso")).endswith("CNNTorso"):
-                    raise NotImplementedError("CNN torsos are built for the feed-forward systems (network=cnn), not for rcnn")
+            if is_cnn(nc.post_torso):
+                raise ValueError("post_torso cannot be a CNNTorso: it consumes the hidden features (network/rcnn.yaml uses an MLPTorso)")
+            if is_cnn(nc.pre_torso):
+                return CNNTorso(**cfgs[0]), GenericMLPTorso(**cfgs[1])
             default = all(list(c.get("layer_sizes", [128])) == [128] and c.get("activation", "relu") == "relu"
                           and not c.get("use_layer_norm", False) for c in cfgs)
             return tuple((MLPTorso if default else GenericMLPTorso)(**c) for c in cfgs)
 
         mk = lambda c: None
         hsd = int(net.get("hidden_state_dim", 128))
-        self.actor_network = RecurrentActor(*torsos(net.actor_network), action_head, self.Oa, hsd)
-        self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd)
+        env0 = self.reps[0].env
+        obs_shape = getattr(env0, "obs_shape", None)  # (H, W, C) observations for CNN pre-torsos (env.synthetic.obs_shape)
+        state_shape = getattr(env0, "state_shape", None) if centralised_critic else obs_shape
+        self.actor_network = RecurrentActor(*torsos(net.actor_network), action_head, self.Oa, hsd, obs_shape)
+        self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd, state_shape)
         self.generic_nets = self.actor_network.generic or self.critic_network.generic
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
         self.P = self.Pa + self.Pc
@@ -429,7 +435,7 @@ class RecLearner:
         """Make the parameter / optimiser buffers equal to `state` (no-op for trees that already alias them), so
         that learn() follows its argument like the reference's pure learner_fn - e.g. params restored from a
         checkpoint (rec_mappo.py:558-566).  Environment and hidden state stay with the learner."""
-        pa = state.params.actor_params["params"]["pre_torso"]["Dense_0"]["kernel"]
+        pa = next(iter(state.params.actor_params["params"]["pre_torso"].values()))["kernel"]  # Dense_0 | Conv_0: the flat buffer's start
         if not isinstance(pa, torch.Tensor) or pa.data_ptr() != self.p.data_ptr():
             dev = self.p.device
             to = lambda tree: self._tree_to(tree, dev)

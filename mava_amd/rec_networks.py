@@ -56,18 +56,21 @@ class RecWorkspace:
 class _RecurrentNet:
     head_scale = 1.0
 
-    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None):
+    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None, obs_shape=None):
         if hidden_state_dim != H:
             raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
         self.din, self.n_out = int(din), int(n_out)
         # Torsos other than network/rnn.yaml's [128] relu (any layer sizes, tanh, layer norm: mava/networks.py:39-58) run on
         # the general layer kernels (mava_amd/generic_networks.py) around the same GRU scans; the fused acting step and the
         # fused output path are for the default torsos only.
-        from .generic_networks import GenericMLPTorso, GenericNet
+        from .generic_networks import CNNTorso, GenericMLPTorso, GenericNet
 
-        self.generic = isinstance(pre_torso, GenericMLPTorso) or isinstance(post_torso, GenericMLPTorso)
+        self.generic = isinstance(pre_torso, (GenericMLPTorso, CNNTorso)) or isinstance(post_torso, GenericMLPTorso)
         if self.generic:
-            self.pre = GenericNet(pre_torso, self.din, [])
+            if isinstance(post_torso, CNNTorso):
+                raise ValueError("post_torso consumes the 128 hidden features: it cannot be a CNNTorso (network/rcnn.yaml: MLPTorso)")
+            # network/rcnn.yaml: CNNTorso pre-torso on (H, W, C) observations (im2col + the same products, section 3.11)
+            self.pre = GenericNet(pre_torso, self.din, [], obs_shape=obs_shape if isinstance(pre_torso, CNNTorso) else None)
             self.post = GenericNet(post_torso, H, [("head", self.n_out, self.head_scale)])
             Np, off = self.pre.feat, self.pre.num_params
             segs = []
@@ -391,8 +394,8 @@ class RecurrentActor(_RecurrentNet):
     head_scale = 0.01
 
     def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head, obs_dim: int,
-                 hidden_state_dim: int = 128):
-        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim, pre_torso, post_torso)
+                 hidden_state_dim: int = 128, obs_shape=None):
+        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim, pre_torso, post_torso, obs_shape)
         self.continuous = isinstance(action_head, ContinuousActionHead)
         if self.continuous:
             self.num_params += self.n_out
@@ -429,8 +432,8 @@ class RecurrentValueNet(_RecurrentNet):
     head_scale = 1.0
 
     def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, centralised_critic: bool, input_dim: int,
-                 hidden_state_dim: int = 128):
-        super().__init__(input_dim, 1, hidden_state_dim, pre_torso, post_torso)
+                 hidden_state_dim: int = 128, obs_shape=None):
+        super().__init__(input_dim, 1, hidden_state_dim, pre_torso, post_torso, obs_shape)
         self.centralised_critic = centralised_critic
 
     def _head_tree(self, head):

@@ -42,15 +42,36 @@ def rec_param_count(din, no: int) -> int:
 # ---- configurable pre / post torsos (mava/networks.py:39-58 MLPTorso inside RecurrentActor / RecurrentValueNet, :269-331):
 # wherever these functions take `din`, a dict from rec_spec() selects torsos other than network/rnn.yaml's [128] relu.
 # Flat layout = mava_amd/rec_networks.py's general layout: [pre torso layers | Wi | bi | Wh | bhn | post torso layers | head].
-def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False):
-    return dict(din=int(din), pre=list(pre_sizes), post=list(post_sizes), act=activation, ln=bool(layer_norm))
+def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False, pre_cnn=None):
+    """pre_cnn = dict(shape=(H, W, C), channels, kernels, strides): a CNNTorso pre-torso (mava/networks.py:61-85, configs/network/
+    rcnn.yaml) instead of the MLP one; its flattened features feed the GRU."""
+    return dict(din=int(din), pre=list(pre_sizes or []), post=list(post_sizes), act=activation, ln=bool(layer_norm), pre_cnn=pre_cnn)
+
+
+def _pre_spec(spec):
+    from . import generic_oracle as go
+
+    c = spec.get("pre_cnn")
+    if c:
+        return go.spec_cnn(c["shape"], c["channels"], c["kernels"], c["strides"], [], spec["act"], spec["ln"])
+    return go.spec_mlp(spec["din"], spec["pre"], [], spec["act"], spec["ln"])
+
+
+def _pre_width(spec) -> int:
+    c = spec.get("pre_cnn")
+    if not c:
+        return spec["pre"][-1]
+    Hh, Ww, C = c["shape"]
+    for co, st in zip(c["channels"], c["strides"]):
+        Hh, Ww, C = -(-Hh // st), -(-Ww // st), co
+    return Hh * Ww * C
 
 
 def _spec_counts(spec, no):
     from . import generic_oracle as go
 
-    n_pre = go.param_count(go.spec_mlp(spec["din"], spec["pre"], [], spec["act"], spec["ln"]))
-    np_ = spec["pre"][-1]
+    n_pre = go.param_count(_pre_spec(spec))
+    np_ = _pre_width(spec)
     n_gru = np_ * 3 * H + 3 * H + H * 3 * H + H
     n_post = go.param_count(go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"]))
     return n_pre, n_gru, n_post, n_pre + n_gru + n_post
@@ -60,8 +81,8 @@ def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, d
     from . import generic_oracle as go
 
     n_pre, n_gru, n_post, _ = _spec_counts(spec, no)
-    np_ = spec["pre"][-1]
-    pre_spec = go.spec_mlp(spec["din"], spec["pre"], [], spec["act"], spec["ln"])
+    np_ = _pre_width(spec)
+    pre_spec = _pre_spec(spec)
     post_spec = go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"])
     g = flat[n_pre : n_pre + n_gru]
     o = 0

@@ -508,8 +508,12 @@ def test_fused_rec_step_matches_oracle(dev, E, A, din, S, nA, share):
     assert_close(logp.cpu().numpy()[:R], lsm[np.arange(R), a], 1e-5, "log_prob")
 
 
+RCNN = dict(shape=(2, 7, 1), channels=[8, 8], kernels=[3, 3], strides=[1, 1])  # network/rcnn.yaml-style CNN pre-torso: 14 = A + O inputs
+
+
 @pytest.mark.parametrize("matmul", ["f32", "f16x2"])
-@pytest.mark.parametrize("system,pre,post,act,ln", [("rec_mappo", [64, 96], [64], "tanh", True), ("rec_ippo", [128], [96, 32], "relu", False)])
+@pytest.mark.parametrize("system,pre,post,act,ln", [("rec_mappo", [64, 96], [64], "tanh", True), ("rec_ippo", [128], [96, 32], "relu", False),
+                                                    ("rec_ippo", RCNN, [64], "tanh", False)], ids=["mappo-mlp-tanh-ln", "ippo-mlp-relu", "ippo-rcnn"])
 def test_rec_learner_general_torsos(dev, system, pre, post, act, ln, matmul):
     """Recurrent systems with pre / post torsos other than network/rnn.yaml's [128] relu (mava/networks.py:39-58 inside
     RecurrentActor / RecurrentValueNet): the general layer kernels around the same GRU scans, whole updates against the
@@ -528,22 +532,38 @@ def test_rec_learner_general_torsos(dev, system, pre, post, act, ln, matmul):
     cfg.system.num_updates_per_eval = 2
     cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
     cfg.system.matmul_mode = matmul
+    cnn = isinstance(pre, dict)
     for nc in (cfg.network.actor_network, cfg.network.critic_network):
-        nc.pre_torso.layer_sizes, nc.post_torso.layer_sizes = pre, post
+        nc.post_torso.layer_sizes = post
+        if cnn:  # configs/network/rcnn.yaml: CNNTorso pre-torso (mava/networks.py:61-85), MLPTorso post-torso
+            nc.pre_torso._target_ = "mava.networks.CNNTorso"
+            del nc.pre_torso["layer_sizes"]
+            nc.pre_torso.channel_sizes, nc.pre_torso.kernel_sizes, nc.pre_torso.strides = pre["channels"], pre["kernels"], pre["strides"]
+        else:
+            nc.pre_torso.layer_sizes = pre
         for t in (nc.pre_torso, nc.post_torso):
             t.activation, t.use_layer_norm = act, ln
+    if cnn:
+        cfg.env.synthetic["obs_shape"] = list(pre["shape"])
     central = system == "rec_mappo"
     mod = rec_mappo if central else rec_ippo
     env, _ = envs.make(cfg, add_global_state=central, device=dev)
     learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
     L = learn.learner
     Oc = A * O if central else A + O
-    spec_a, spec_c = ro.rec_spec(A + O, pre, post, act, ln), ro.rec_spec(Oc, pre, post, act, ln)
+    if cnn:
+        spec_a, spec_c = ro.rec_spec(A + O, None, post, act, ln, pre_cnn=pre), ro.rec_spec(Oc, None, post, act, ln, pre_cnn=pre)
+    else:
+        spec_a, spec_c = ro.rec_spec(A + O, pre, post, act, ln), ro.rec_spec(Oc, pre, post, act, ln)
     assert L.generic_nets and not L.fused_out
     assert L.Pa == ro.rec_param_count(spec_a, nA) and L.Pc == ro.rec_param_count(spec_c, 1)
     tree = state.params.actor_params["params"]
-    assert tree["pre_torso"]["Dense_0"]["kernel"].shape == (1, U, A + O, pre[0])
-    assert tree["ScannedRNN_0"]["GRUCell_0"]["ir"]["kernel"].shape == (1, U, pre[-1], 128)
+    if cnn:
+        assert int(np.prod(tree["pre_torso"]["Conv_0"]["kernel"].shape[2:])) == 3 * 3 * 1 * 8
+        assert tree["ScannedRNN_0"]["GRUCell_0"]["ir"]["kernel"].shape == (1, U, 2 * 7 * 8, 128)
+    else:
+        assert tree["pre_torso"]["Dense_0"]["kernel"].shape == (1, U, A + O, pre[0])
+        assert tree["ScannedRNN_0"]["GRUCell_0"]["ir"]["kernel"].shape == (1, U, pre[-1], 128)
     assert ("LayerNorm_0" in tree["post_torso"]) == ln
     assert torch.equal(actor_network.flat_from_tree(state.params.actor_params), L.p[: L.Pa])
 

@@ -16,11 +16,11 @@ names = ["P1 layer1", "P2 layer2+head", "P3 loss+dz2", "P4 dh1+sweeps", "P4b dz1
 # note: with sub-stamps, "P1 layer1" = epilogue after P1a, "P2 layer2+head" = head part after P2b
 if MODE == 1:  # phases of ppo_train_h2.hip
     names = ["P1 mfma", "P1 relu+image", "gather issue", "barrier A", "P2 mfma", "P2 image+head", "barrier B", "P3 loss",
-             "B2+dz2+image", "barrier C", "P4 mfma+dz1+commit", "gW3+gW2", "barrier D", "gW1", "loop top", "-"]
+             "B2+dz2+image", "barrier C", "P4 mfma+dz1+commit", "gW3+gW2", "barrier D", "gW1 (wide chain: gW2)", "loop top", "barrier B2"]
 l = lib()
 l.mava_ppo_set_matmul_mode(MODE)
 l.mava_debug_set_stamps.argtypes = [C.c_void_p]
-stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+stamps = torch.zeros(128, dtype=torch.int64, device=dev)  # waves 0-3 (chain / only group), 4-7 (loader group of wide launches)
 l.mava_debug_set_stamps(stamps.data_ptr())
 perm = torch.randperm(TE, device=dev).to(torch.int32)
 for which in ("critic", "actor"):
@@ -46,11 +46,14 @@ for which in ("critic", "actor"):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); run(); b.record(); torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(4, 16)
+    s8 = stamps.cpu().numpy().reshape(8, 16)
+    s = s8[:4]
     tot = s.sum(1)
     # row tiles per block: agent rows for the actor; (t,e) rows for the critic when the agents of a row are aggregated
     rows = Rb * A if which == "actor" else Rb
     ntile = -(-rows // 32 // 256)
     print(f"== {which}: launch {a.elapsed_time(b):.3f} ms, block 0 cycles per wave {tot.tolist()}, {ntile} tiles per block")
     for i, n in enumerate(names):
-        print(f"   {n:16s} " + "  ".join(f"{s[w, i] / ntile:8.0f}" for w in range(4)) + f"   ({100 * s[0, i] / tot[0]:5.1f} %)")
+        print(f"   {n:24s} " + "  ".join(f"{s[w, i] / ntile:8.0f}" for w in range(4)) + f"   ({100 * s[0, i] / tot[0]:5.1f} %)"
+              + (f"   loader wave 4: {s8[4, i] / ntile:8.0f}" if s8[4].sum() > 0 else ""))
+    stamps.zero_()

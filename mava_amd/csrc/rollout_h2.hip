@@ -26,8 +26,26 @@
 // phases use all 512 threads.  LDS only holds activations.
 #include "h2_core.h"
 
+#ifdef MAVA_STAMPS
+// phase stamps (diagnostic build): cycles per phase of wave 0 of each role of block 0, summed over the T steps
+#define RSTAMP_DECL unsigned long long rs_prev = __builtin_readcyclecounter(), rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RSTAMP(i)                                                   \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long rs_now = __builtin_readcyclecounter(); \
+    rs_acc[i] += rs_now - rs_prev;                                  \
+    rs_prev = rs_now;                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+static __device__ unsigned long long g_rollout_stamps[16];
+#else
+#define RSTAMP_DECL
+#define RSTAMP(i)
+#endif
+
 namespace {
 using namespace h2;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t ENV_STREAM = 0x454E5653u;   // "ENVS" (synth_rware.hip)
 constexpr uint32_t POLICY_STREAM = 0x504f4c49u;  // "POLI" (mlp_policy.hip)
@@ -224,6 +242,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   // one pass of THIS ROLE's network over the x images: layer 1, layer 2, head partials (two barriers inside, the same
   // for both roles; `active` = false keeps only the barriers: the actor group during the bootstrap pass)
   constexpr int NT = ACT_ROLE ? 2 : NTC;  // 32-row tiles of this role
+  RSTAMP_DECL
   auto forward = [&](bool active) __attribute__((always_inline)) {
     f32x16 z[NT];
 #pragma unroll
@@ -257,7 +276,9 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         write_image(lds + L.h1 + ((ACT_ROLE ? 0 : 2) + i) * IMG_BYTES, r, 32 * w + 4 * h, z[i], ph, pl);
       }
     }
+    RSTAMP(0);
     __syncthreads();  // barrier 1: h1 images complete
+    RSTAMP(1);
     if (active) {
       const float* b2 = ACT_ROLE ? B2a : B2c;
 #pragma unroll
@@ -315,11 +336,79 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         }
       }
     }
+    RSTAMP(2);
     __syncthreads();  // barrier 2: head partials complete
+    RSTAMP(3);
   };
   auto value_of = [&](int crow) -> float {  // critic row (env for SHARED, agent row otherwise) of this block
     const float* yp = YPC + (crow >> 5) * 4 * 32 + (crow & 31);
     return (((yp[0] + yp[32]) + yp[64]) + yp[96]) + B3c[0];
+  };
+
+  // Trajectory copy of the observation the x images hold (critic group, 256 threads): the block's rows are contiguous in
+  // every array, so consecutive lanes store consecutive floats - agents_view (64 rows x W), the global state (EB envs x
+  // A * O, the shared critic's image) and the action mask (64 rows x no bytes).  Row / column cursors advance without
+  // divisions.
+  const int rows_ok = min(64, (E - e0) * A), envs_ok = min(EB, E - e0);  // valid rows / envs of this block
+  const int AO = A * O;
+  auto write_out = [&](long slot) {
+    {
+      float* dst = a.agents_view + (slot * EA + (long)e0 * A) * W;
+      if ((W & 1) == 0) {  // pairs: 4-byte LDS reads, 8-byte stores (row bases are multiples of 8 bytes)
+        const int W2 = W >> 1, d_r = 256 / W2, d_f = 256 - d_r * W2;
+        int row = tid / W2, f = tid - row * W2;
+        for (int j = tid; j < 64 * W2; j += 256) {
+          if (row < rows_ok) {
+            const u8* xa = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row;
+            const half2v v = *reinterpret_cast<const half2v*>(xa + 4 * f);
+            reinterpret_cast<float2*>(dst)[j] = make_float2((float)v[0], (float)v[1]);
+          }
+          row += d_r; f += d_f;
+          if (f >= W2) { f -= W2; ++row; }
+        }
+      } else {
+        const int d_r = 256 / W, d_f = 256 - d_r * W;
+        int row = tid / W, f = tid - row * W;
+        for (int j = tid; j < 64 * W; j += 256) {
+          if (row < rows_ok) {
+            const u8* xa = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row;
+            dst[j] = (float)*reinterpret_cast<const _Float16*>(xa + 2 * f);
+          }
+          row += d_r; f += d_f;
+          if (f >= W) { f -= W; ++row; }
+        }
+      }
+    }
+    if (SHARED && a.global_state != nullptr) {
+      float* dst = a.global_state + (slot * E + e0) * (long)AO;
+      if ((AO & 3) == 0) {  // quads: 8-byte LDS reads, 16-byte stores
+        const int Q = AO >> 2, d_r = 256 / Q, d_f = 256 - d_r * Q;
+        int le = tid / Q, k = tid - le * Q;
+        for (int j = tid; j < EB * Q; j += 256) {
+          if (le < envs_ok) {
+            const half4 v = *reinterpret_cast<const half4*>(lds + L.xc + le * xc_row + 8 * k);
+            reinterpret_cast<float4*>(dst)[j] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+          }
+          le += d_r; k += d_f;
+          if (k >= Q) { k -= Q; ++le; }
+        }
+      } else {
+        const int d_r = 256 / AO, d_f = 256 - d_r * AO;
+        int le = tid / AO, k = tid - le * AO;
+        for (int j = tid; j < EB * AO; j += 256) {
+          if (le < envs_ok) dst[j] = (float)*reinterpret_cast<const _Float16*>(lds + L.xc + le * xc_row + 2 * k);
+          le += d_r; k += d_f;
+          if (k >= AO) { k -= AO; ++le; }
+        }
+      }
+    }
+    {
+      uint8_t* dst = a.action_mask + (slot * EA + (long)e0 * A) * no;
+      for (int j = tid; j < rows_ok * no; j += 256) {
+        const int row = j / no, o = j - row * no;
+        dst[j] = MASK[row * 32 + o];
+      }
+    }
   };
 
   for (int t = 0; t < a.T; ++t) {
@@ -374,8 +463,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
       if (tid < 64 && (e0 + tid / A) < E) {
         a.value[(long)t * EA + (long)e0 * A + tid] = value_of(SHARED ? tid / A : tid);
       }
+      if (t > 0) write_out((long)t);  // slot t = what the env phase of step t - 1 produced (slot 0 came from memory)
     }
+    RSTAMP(4);
     __syncthreads();  // barrier 3: actions visible to the env phase; every reader of the x images is done
+    RSTAMP(5);
     // ---------------------------------------------------------------- E: env.step -> slot t + 1 (HBM f32 + LDS images)
     {
       const uint32_t tn = step + 1;
@@ -388,29 +480,26 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         const uint32_t ent = (a.env_offset + e) * A + ag;
         const Philox4 rv = philox4x32_10(ent, tn, c, ENV_STREAM, a.eseed_lo, a.eseed_hi);
         const uint32_t wds[4] = {rv.x, rv.y, rv.z, rv.w};
+        // The new observation goes into the LDS x images only (every value - 0 / 1 bits, the two counters 0..9, the
+        // one-hot agent id - is exact in f16, the lo plane stays zero).  Its f32 copy in the trajectory (slot t + 1) is
+        // written from the images by the critic group during the NEXT step's sample phase (write_out below): stored
+        // from here, one 4-byte piece per lane 64 bytes apart, every store instruction touched 64 cache lines and the
+        // env phase was 15.4 K of a step's 28.8 K cycles (phase stamps).
         const uint32_t f0 = 2 + 16 * c;
         const int n = (int)min(16u, (uint32_t)O - f0);
-        float* av = a.agents_view + (slot * EA + (long)e * A + ag) * W;
-        float* gs = a.global_state ? a.global_state + (slot * E + e) * ((long)A * O) + (long)ag * O : nullptr;
         u8* xa = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row;
         u8* xc = lds + L.xc + le * xc_row + 2 * (ag * O);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           if (q < n) {
             const float v = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
-            av[A + f0 + q] = v;
-            if (gs) gs[f0 + q] = v;
-            *reinterpret_cast<_Float16*>(xa + 2 * (A + f0 + q)) = (_Float16)v;  // exact: the lo plane stays zero
+            *reinterpret_cast<_Float16*>(xa + 2 * (A + f0 + q)) = (_Float16)v;
             if (SHARED) *reinterpret_cast<_Float16*>(xc + 2 * (f0 + q)) = (_Float16)v;
           }
         }
         if (c == 0) {
           const Philox4 cm = philox4x32_10(ent, tn, 0xFFFFu, ENV_STREAM, a.eseed_lo, a.eseed_hi);
           const float c0 = (float)(cm.x % 10u), c1 = (float)(cm.y % 10u);
-          for (uint32_t k2 = 0; k2 < (uint32_t)A; ++k2) av[k2] = (k2 == ag) ? 1.0f : 0.0f;
-          av[A] = c0;
-          av[A + 1] = c1;
-          if (gs) { gs[0] = c0; gs[1] = c1; }
           *reinterpret_cast<_Float16*>(xa + 2 * A) = (_Float16)c0;
           *reinterpret_cast<_Float16*>(xa + 2 * (A + 1)) = (_Float16)c1;
           if (SHARED) {
@@ -418,13 +507,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
             *reinterpret_cast<_Float16*>(xc + 2) = (_Float16)c1;
           }
           // action mask of the new observation: all legal except action 1 w.p. 51/256
-          uint8_t* mk = a.action_mask + (slot * EA + (long)e * A + ag) * no;
           const bool m1 = !((cm.z & 0xFFu) < 51u);
-          for (int o = 0; o < no; ++o) {
-            const uint8_t mv = (o == 1 && no > 1) ? (m1 ? 1 : 0) : 1;
-            mk[o] = mv;
-            MASK[row * 32 + o] = mv;
-          }
+          for (int o = 0; o < no; ++o) MASK[row * 32 + o] = (o == 1 && no > 1) ? (m1 ? 1 : 0) : 1;
         }
       }
       if (bk_on) {
@@ -460,9 +544,16 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         }
       }
     }
+    RSTAMP(6);
     __syncthreads();  // barrier 4: x images of slot t + 1 complete
+    RSTAMP(7);
   }
+#ifdef MAVA_STAMPS
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) g_rollout_stamps[(ACT_ROLE ? 0 : 8) + i] = rs_acc[i];
+#endif
   // ------------------------------------------------------------------ bootstrap value (ff_mappo.py:109-110)
+  if (!ACT_ROLE) write_out((long)a.T);  // the last observation
   forward(!ACT_ROLE);
   if (bk_on) {
     const float lv = value_of(SHARED ? tid / A : tid);
@@ -534,6 +625,13 @@ int launch_rollout(const RolloutArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef MAVA_STAMPS
+// diagnostic builds: copies the 2 x 8 phase sums of the last launch (actor role, critic role) to the host
+extern "C" int mava_debug_get_rollout_stamps(unsigned long long* out16) {
+  return -(int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rollout_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* critic_params, int critic_shared,
                                    int E, int A, int O, int T, int time_limit, uint64_t policy_seed, uint64_t env_seed,

@@ -201,7 +201,13 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   // ---------------------------------------------------------------- weight fragments kept in registers
   // layer 1 (A operand): W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din is zero.  Narrow inputs: all S1
   // steps resident; WIDE: a ring of W1_RING steps fed from the pre-split global copy.
-  constexpr int NW1 = !CHAIN ? 1 : (WIDE ? W1_RING : S1);
+  // WIDE: layer 1 is split along its input index between the two groups - the chain group takes steps [0, S1 / 2), the
+  // loader group (idle during P1 otherwise) [S1 / 2, S1) - each through its own ring; the loader's partial sums cross in
+  // LDS (barrier A0).  The ring is latency-bound (3 steps x 2 KB in flight per wave against a ~700-cycle L2 round trip:
+  // 6.0 K cycles per tile for 1.7 K of MFMAs with one group); the second group doubles the bytes in flight.
+  constexpr int S_LO = (WIDE && !CHAIN) ? S1 / 2 : 0, S_HI = (WIDE && CHAIN) ? S1 / 2 : S1, RL = S_HI - S_LO;
+  static_assert(!WIDE || ((S1 / 2) % W1_RING == 0 && (S1 - S1 / 2) % W1_RING == 0), "WIDE: both halves must be multiples of the ring");
+  constexpr int NW1 = WIDE ? W1_RING : (CHAIN ? S1 : 1);
   Frag W1f[NW1];
   // The fragment of step s sits 8 KB x s behind this lane's base: too far for an instruction immediate.  Written against a
   // loop-invariant base the compiler forms one 64-bit address per step, hoists all of them out of the tile loop and spills
@@ -217,9 +223,9 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   };
   float w1_carry = 0.0f;
 #pragma unroll
-  for (int s = 0; s < (CHAIN ? NW1 : 0); ++s) {
+  for (int s = 0; s < (CHAIN ? NW1 : 0); ++s) {  // (the loader group of WIDE launches fills its ring at the start of each P1)
     if (WIDE) {
-      W1f[s] = w1_fetch(s);
+      W1f[s] = w1_fetch(S_LO + s);
     } else {
       float v[8];
 #pragma unroll
@@ -282,7 +288,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   const int lo = ACTOR ? (lane & (NO - 1)) : 0;
   auto loss_row = [&](int q) -> int { return ACTOR ? (8 * w + q * GR + lane / NO) : r; };
   const int slot = 2 * w + h;
-  const int slot_c = (!ACTOR && tk.agg > 1) ? (slot < tk.agg ? slot : 0) : 0;
+  uint32_t slot_c = (!ACTOR && tk.agg > 1) ? (uint32_t)(slot < tk.agg ? slot : 0) : 0u;
   auto load_row = [&](long fr, int& act, float& f0, float& f1, uint32_t& m) {
     if (ACTOR) {
       act = tk.action[fr];
@@ -293,7 +299,8 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
       if (mk != nullptr) m = *mk;
     } else {
       act = 0;
-      const long fa = (tk.agg > 1) ? fr * tk.agg + slot_c : fr;
+      // (32-bit row arithmetic, rows < 2^31: a 64-bit lane constant here was hoisted, spilled and reloaded per tile)
+      const long fa = (tk.agg > 1) ? (long)((uint32_t)fr * (uint32_t)tk.agg + slot_c) : fr;
       f0 = tk.old_value[fa];
       f1 = tk.targets[fa];
       m = 0u;
@@ -462,25 +469,48 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x16 acc;
     uint32_t relu1 = 0;
-    if constexpr (WIDE && CHAIN) asm volatile("" : "+v"(w1p_lane));  // (see w1_fetch: its addresses stay loop-variant)
-    if constexpr (CHAIN) {
+    if constexpr (WIDE) asm volatile("" : "+v"(w1p_lane));  // (see w1_fetch: its addresses stay loop-variant)
+    if constexpr (CHAIN || WIDE) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
     // operand reads run ONE step ahead of their MFMAs (explicit double buffer + scheduling fence: without it the
     // compiler hoists every read of the unrolled loop and spills)
-    Frag xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h);
+    if constexpr (WIDE && !CHAIN) {
+      // the loader group's ring does not live across the tile (its registers hold the next x tile from the gather issue to
+      // the commit): filled here, one exposed L2 round trip per tile in a group that would otherwise wait at barrier A0
 #pragma unroll
-    for (int s = 0; s < S1; ++s) {
+      for (int s = 0; s < NW1; ++s) W1f[s] = w1_fetch(S_LO + s);
+    }
+    Frag xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * S_LO);
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {  // this group's steps s = S_LO + j
       const Frag b = xb;
-      if (s + 1 < S1) xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * (s + 1));
-      acc = mfma3(W1f[s % NW1], b, acc);
+      if (j + 1 < RL) xb = read_row_frag(XSI, xs_plane, r * xs_row + 16 * h + 32 * (S_LO + j + 1));
+      acc = mfma3(W1f[j % NW1], b, acc);
       if (WIDE) {
-        // refill the slot consumed one step ago with step s - 1 + W1_RING (wrapping to the head steps of the next tile)
-        if (s >= 1) W1f[(s - 1) % NW1] = w1_fetch((s - 1 + W1_RING) % S1);
+        // refill the slot consumed one step ago with step j - 1 + W1_RING of this tile
+        if (j >= 1 && j - 1 + W1_RING < RL) W1f[(j - 1) % NW1] = w1_fetch(S_LO + j - 1 + W1_RING);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (WIDE) W1f[(S1 - 1) % NW1] = w1_fetch((S1 - 1 + W1_RING) % S1);
+    }
+    if constexpr (WIDE) {
+      // the loader group's partial sums of its input range -> the chain group (the dz2 image region is idle here)
+      float4* const xch = reinterpret_cast<float4*>(DZ2I) + (w * 4) * 64 + lane;
+      if constexpr (LOADER) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xch[g * 64] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      }
+      __syncthreads();  // A0
+      if constexpr (CHAIN) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = xch[g * 64];
+          acc[4 * g] += v.x; acc[4 * g + 1] += v.y; acc[4 * g + 2] += v.z; acc[4 * g + 3] += v.w;
+        }
+      }
+    }
+    if constexpr (CHAIN) {
     STAMP(0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -494,24 +524,53 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     }  // CHAIN
     STAMP(1);
     // next tile's gathers: issued after P1 (their latency hides under P2..P4)
-    if (have_next) {
-      if (LOADER) stage_issue(xrow_next, xr);
-      if (CHAIN) {
+    if constexpr (WIDE && LOADER) {
+      // unconditional (row 0 when there is no next tile): the staging registers are then dead from the commit to here,
+      // and P1's ring and accumulator live in them
+      stage_issue(have_next ? xrow_next : 0u, xr);
+    }
+    if constexpr (WIDE && CHAIN) {
+      // everything the gather block reads is pinned into registers here, before its first load: reloads of spilled values
+      // (each followed by s_waitcnt vmcnt(0)) then find no gather of this block in flight
 #pragma unroll
-        for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+      for (int q = 0; q < NP; ++q) {
+        asm volatile("" : "+v"(fr_next[q]));
+        asm volatile("" : "+v"(cl[q].q), "+v"(cl[q].b), "+v"(cl[q].a));
       }
-      if (itn + gridDim.x < ntiles) {
+      asm volatile("" : "+v"(slot_c));
+    }
+    if (have_next) {
+      if (LOADER && !WIDE) stage_issue(xrow_next, xr);
+      const bool more = itn + gridDim.x < ntiles;
+      if (more) {
         if (LOADER) {
           cursor_gather(cs, ps_next, as_next);
           cursor_advance(cs);
         }
         if (CHAIN) {
+          // cursor arithmetic first, loads after it: a cursor value that was spilled comes back with s_waitcnt vmcnt(0),
+          // which must not find this block's own gathers in flight (2.4 K cycles per tile in the wide chain role)
+          Cursor c_old[NP];
 #pragma unroll
-          for (int q = 0; q < NP; ++q) cursor_gather(cl[q], pl_next[q], al_next[q]);
+          for (int q = 0; q < NP; ++q) { c_old[q] = cl[q]; cursor_advance(cl[q]); }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < NP; ++q) cursor_advance(cl[q]);
+          for (int q = 0; q < NP; ++q) cursor_gather(c_old[q], pl_next[q], al_next[q]);
         }
       }
+      if (CHAIN) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) load_row((long)fr_next[q], n_act[q], n_f0[q], n_f1[q], n_m[q]);
+      }
+    }
+    if constexpr (WIDE && CHAIN) {
+      // the chain group's ring for the NEXT tile (steps 0 .. W1_RING - 1: a whole tile of latency to hide under).  Issued
+      // here, behind the gather block: a spilled cursor value reloaded there comes with s_waitcnt vmcnt(0), which waited
+      // for these fetches when they were issued at the end of the P1 loop (3.0 K cycles per tile)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < NW1; ++s2) W1f[s2] = w1_fetch(S_LO + s2);
+      __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(2);
     __syncthreads();  // A: h1 image complete
@@ -820,7 +879,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if constexpr (WIDE) {
       __syncthreads();  // E: every reader of the (single) x tile is done
       if constexpr (LOADER) {
-        if (have_next) stage_commit(0, xr);
+        stage_commit(0, xr);  // (without a next tile: row 0 into a buffer nobody reads again)
       }
       __syncthreads();  // F: next x tile visible
     }

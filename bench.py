@@ -269,7 +269,7 @@ def main() -> None:
     # run - it is attached from the committed rocprofv3 PMC pass of the same workload named in `traffic_source`
     # (regenerated per round with tools/pmc_traffic.sh; stale once a kernel changes after that pass).
     traffic, traffic_source = {}, None
-    for name in ("r02_v4_pmc_traffic.json", "r02_v3_pmc_traffic.json", "r02_v2_pmc_traffic.json", "r02_v1_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
+    for name in ("r02_v5_pmc_traffic.json", "r02_v4_pmc_traffic.json", "r02_v3_pmc_traffic.json", "r02_v2_pmc_traffic.json", "r02_v1_pmc_traffic.json", "r01_v5_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["kernels"]

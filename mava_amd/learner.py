@@ -553,7 +553,7 @@ class FFLearner:
         self._rollout(n)
         # advantage statistics of ALL K x M minibatches in one launch per replica (the permutations are this learner's
         # own contiguous buffer: minibatch (k, mb) = slice k * M + mb of it); otherwise one launch per minibatch
-        self._stats_batched = own and not self.generic
+        self._stats_batched = own and not self.generic and self.T * self.E == self.M * self.Rb  # (slices tile the buffer)
         if self._stats_batched:
             for u, rep in enumerate(self.reps):
                 ops.adv_stats_batched(rep.adv.view(-1), self._perm_all.view(-1), self.Rb, self.A, self.K * self.M,

@@ -128,8 +128,20 @@ def test_learner_update_matches_oracle(dev, system, U, rollout, matmul, monkeypa
 
     for i in range(4):  # update 2 captures the rollout graph, updates 3 and 4 replay it (for n = 0 and n = 1)
         n = i % 2
-        perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
-        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        if i < 3:
+            perms = [rng.permutation(T * E).astype(np.int32) for _ in range(K)]
+            L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        else:
+            # the production path: the learner draws its own epoch permutations (mava_permutation_i32, keyed by the seed
+            # and a running counter) and takes the advantage statistics of all K x M minibatches from one batched launch
+            from oracle.permutation import permutation
+
+            c0 = L.perm_count
+            L.update(n)
+            assert L._stats_batched and L.perm_count == c0 + K
+            perms = [b.cpu().numpy() for b in L._perm_bufs]
+            for k_, p in enumerate(perms):
+                assert np.array_equal(p, permutation(T * E, L.seed, c0 + k_)), "epoch permutation differs from oracle/permutation.py"
         torch.cuda.synchronize()
         res = ora.update(perms)
         for u in range(U):

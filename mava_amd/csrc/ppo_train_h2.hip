@@ -93,25 +93,27 @@ constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 i
 
 // WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
 // lane (r, h) of wave w holds W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din zero.
-__global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, int steps, uint4* __restrict__ out) {
+template <int STEPS>
+__global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, uint4* __restrict__ out) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  float carry = 0.0f;  // error diffusion along k over this lane's inputs of feature 32w + r (split1_carry)
-  for (int s0 = 0; s0 < steps; s0 += 6) {  // steps is a multiple of 6; six steps' loads in flight at a time
-    float v[6][8];
+  // one block (the error-diffusion carry of split1_carry runs along k over this lane's inputs of feature 32w + r), so the
+  // launch is a chain of memory round trips: every load of the thread (8 x STEPS <= 144 floats) is issued before the first
+  // is used - one round trip instead of one per six steps
+  float v[STEPS][8];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < STEPS; ++i)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = 16 * (s0 + i) + 8 * h + e;
-        v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
-      }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const Frag f = split8_carry(v[i], carry);
-      const int gid = (s0 + i) * 256 + threadIdx.x;
-      out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
-      out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * i + 8 * h + e;
+      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
     }
+  float carry = 0.0f;
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+    const Frag f = split8_carry(v[i], carry);
+    const int gid = i * 256 + threadIdx.x;
+    out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
+    out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
   }
 }
 
@@ -1003,7 +1005,7 @@ int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
   if (WIDE) {
     uint4*& buf = g_w1p[ACTOR ? 0 : 1];
     if (buf == nullptr) MAVA_HIP_CHECK(hipMalloc((void**)&buf, (size_t)18 * 256 * 32));
-    hipLaunchKernelGGL(pack_w1_kernel, dim3(1), dim3(256), 0, s, tk.params, tk.din, S1, buf);
+    hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf);
     MAVA_LAUNCH_CHECK();
     w1p = buf;
   }

@@ -123,7 +123,7 @@ def main() -> None:
                          "(--agents, --obs-dim, --action-dim; SURVEY 8f N4) - a secondary workload, not the headline metric")
     ap.add_argument("--matmul", default="f16x2", choices=["f32", "f16x2"],
                     help="arithmetic of the fused PPO gradient kernels: exact-f32 MFMA, or split-f16 operands (3 f16 MFMAs per "
-                         "product, f32 accumulate; mava_ppo_set_matmul_mode)")
+                         "product, f32 accumulate; MAVA_CTX_MATMUL_MODE of the learner's context handle)")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--obs-dim", type=int, default=27)
     ap.add_argument("--action-dim", type=int, default=2)
@@ -190,9 +190,7 @@ def main() -> None:
             torch.cuda.synchronize()
 
     if args.no_critic_aggregation:
-        from mava_amd._lib import lib as _mava_lib
-
-        _mava_lib().mava_ppo_set_critic_aggregation(0)
+        L.ctx.set(L.ctx.CRITIC_AGGREGATION, 0)
     log(f"setup done: {world} rank(s), E={E} U={U} T={T} A={A} Oa={L.Oa} Oc={L.Oc} matmul={args.matmul}")
     for i in range(args.warmup):
         L.update(0)
@@ -285,7 +283,7 @@ def main() -> None:
         avg = {k: sum(v) / len(v) for k, v in timers.items() if v}
         rows = L.Rb * A  # agent rows per minibatch launch
         # With a centralised critic on a shared global state (x_share == A) the critic kernel evaluates each (t,e)
-        # row once and back-propagates the sum of its agents' loss gradients (mava_ppo_set_critic_aggregation,
+        # row once and back-propagates the sum of its agents' loss gradients (MAVA_CTX_CRITIC_AGGREGATION,
         # default on): its EXECUTED matrix work is 1/A of the reference's A identical passes.  Rooflines are
         # priced on executed FLOPs.
         aggregated = bool(getattr(L, "critic_share", 1) == A and 1 < A <= 8 and not args.no_critic_aggregation)

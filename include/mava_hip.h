@@ -27,21 +27,44 @@ typedef struct ihipStream_t* mava_stream_t; /* hipStream_t */
 const char* mava_last_error(void); /* thread-local text of the last failure */
 int mava_abi_version(void);
 
+/* ---- context handle: the library keeps NO process-wide state ("no hidden globals except handles").
+ * Everything that selects behaviour - the arithmetic of the matrix products, the critic aggregation, kernel variants for
+ * bench sweeps - and every workspace the library allocates itself (the pre-split W1 copy of the wide f16x2 gradient
+ * kernels) belongs to a handle the caller creates per learner and passes as the first argument of the entry points that
+ * depend on it.  NULL is accepted everywhere and means the defaults (exact f32, aggregation on, default variants).  Two
+ * handles share nothing; launches that share one handle must be issued on one stream (they share its W1 workspace).
+ * In Mava the same choices are properties of the jitted learner function (mava/systems/ppo/ff_mappo.py:388-389). */
+typedef struct mava_ctx mava_ctx;
+enum {
+  MAVA_CTX_MATMUL_MODE = 0,        /* 0 (default): exact-f32 MFMA; 1: "f16x2" - every matrix operand split into two f16 terms
+                                      (hi + lo), three f16 MFMAs per product, f32 accumulation: 5.3x less matrix-pipe time, the
+                                      same 1e-4 gradient parity tests; applies where a split-f16 kernel is instantiated
+                                      (ppo_train_h2.hip, rec_dense_h2.hip, rec_gru_h2.hip), other shapes run exact f32 */
+  MAVA_CTX_CRITIC_AGGREGATION = 1, /* 1 (default): a critic input row shared by the A agents of a (t,e) index (RWARE's global
+                                      state, mava/wrappers/jumanji.py:53-59) is evaluated once and the sum of its agents' loss
+                                      gradients back-propagated - the same gradient as A identical passes; 0: one pass per agent */
+  MAVA_CTX_GAE_VARIANT = 2,        /* bench sweeps (tools/gae_sweep.py): chunk / lane mapping of mava_gae_f32, 0 = default */
+  MAVA_CTX_POLICY_VARIANT = 3,     /* 0 = per-wave acting kernel / hybrid launch (default), 1 = per-wave only, 2 = block-cooperative */
+  MAVA_CTX_H2_LAUNCHES = 4         /* diagnostic counter: gradient launches of this handle that ran on the f16x2 kernels */
+};
+int mava_ctx_create(mava_ctx** out);
+int mava_ctx_destroy(mava_ctx* ctx); /* frees the handle's workspaces; NULL is a no-op */
+int mava_ctx_set(mava_ctx* ctx, int key, long value);
+int mava_ctx_get(const mava_ctx* ctx, int key, long* value);
+
 /* ---- GAE: mava/systems/ppo/ff_mappo.py:112-139 (_calculate_gae);
  *           mava/systems/ppo/rec_mappo.py:177-199 when last_done != NULL.
  * reward,value,adv,tgt: (T,N) f32 time-major; done: (T,N) u8; last_val: (N) f32;
  * last_done: (N) u8 or NULL.  Recurrent mode: done[t] is the flag ENTERING step t and the mask
  * of step t is done[t+1] (done[T] := last_done). */
-int mava_gae_f32(const float* reward, const float* value, const uint8_t* done,
+int mava_gae_f32(const mava_ctx* ctx, const float* reward, const float* value, const uint8_t* done,
                  const float* last_val, const uint8_t* last_done, int T, int N, float gamma,
                  float lambda, float* adv, float* tgt, mava_stream_t s);
-int mava_gae_set_variant(int variant); /* bench-only tuning knob, 0 = default */
 
 /* ---- epoch permutation: jax.random.permutation(key, batch_size) of ff_mappo.py:272-273 / rec_mappo.py:277-279.
  * out[0..n) = a bijection of [0, n) determined by (seed, counter): 16-round keyed Feistel network over [0, 2^ceil(log2 n))
  * with cycle walking (mava_amd/csrc/permutation.hip; bit-exact restatement oracle/permutation.py).  1 <= n < 2^31. */
 int mava_permutation_i32(long n, uint64_t seed, uint64_t counter, int32_t* out, mava_stream_t s);
-int mava_policy_set_variant(int variant); /* 0 = per-wave acting kernel (default), 2 = block-cooperative kernels */
 
 /* ---- optimiser: optax.chain(clip_by_global_norm, adam(eps=1e-5)) per network,
  *      mava/systems/ppo/ff_mappo.py:359-366 (definition) and :241-250 (application);
@@ -74,7 +97,7 @@ int mava_slab_reduce2_f32(const float* slab, int n_slab, long slab_stride, int n
 int mava_mlp_param_count(int din, int n_out);
 
 /* out (rows, n_out) = net(x[row / x_share]);  x: (ceil(rows/x_share), din). */
-int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x, int x_share,
+int mava_mlp_forward_f32(const mava_ctx* ctx, const float* params, int din, int n_out, const float* x, int x_share,
                          int rows, float* out, mava_stream_t s);
 
 /* One acting step, mava/systems/ppo/ff_mappo.py:80-85: actor forward + action mask
@@ -90,7 +113,7 @@ int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x
  * replays with the next counters (mava_synth_rware_step takes t_base likewise).
  * rows == 0 or critic_rows == 0 skips that half (its pointers may then be NULL): the learner runs the actor
  * half on the acting stream and the value half (mava_mlp_forward_f32) on a side stream. */
-int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
+int mava_policy_step_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int n_actions,
                          const float* agents_view, const uint8_t* action_mask,
                          const float* critic_params, int critic_din, const float* critic_input,
                          int critic_share, int critic_rows, int value_broadcast, int rows,
@@ -118,7 +141,7 @@ int mava_adv_stats_batched_f64(const float* advantages, const int32_t* idx, long
                                int n_batch, double* partials, mava_stream_t s);
 
 /* _actor_loss_fn, ff_mappo.py:150-180.  slab tail: [actor_loss, entropy]. */
-int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const float* agents_view,
+int mava_ppo_actor_grad_f32(mava_ctx* ctx, const float* params, int din, int n_actions, const float* agents_view,
                             const uint8_t* action_mask, const int32_t* action,
                             const float* old_log_prob, const float* advantages,
                             const double* adv_stats, const int32_t* idx, long idx_base, int Rb,
@@ -136,7 +159,7 @@ int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions, const f
  * mava_ppo_actor_grad_continuous_f32: _actor_loss_fn ff_mappo.py:150-180 for this head; the entropy sample of
  * ff_mappo.py:176-177 is drawn from Philox(counter (row_offset + trajectory row, ent_step, dim/2), key seed).
  * slab row = [MLP gradient | d/d log_std | actor_loss, entropy]. */
-int mava_policy_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int action_dim,
                                     const float* agents_view, const float* critic_params, int critic_din,
                                     const float* critic_input, int critic_share, int critic_rows,
                                     int value_broadcast, int rows, uint64_t seed, uint32_t step,
@@ -152,23 +175,12 @@ int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_
 
 /* _critic_loss_fn, ff_mappo.py:182-201.  critic_input row = agent_row / x_share.
  * slab tail: [value_loss, unused]. */
-int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_input, int x_share,
+int mava_ppo_critic_grad_f32(mava_ctx* ctx, const float* params, int din, const float* critic_input, int x_share,
                              const float* old_value, const float* targets, const int32_t* idx,
                              long idx_base, int Rb, int A, float clip_eps, float vf_coef,
                              float* slab, long slab_stride, int n_slab, mava_stream_t s);
 
-/* Measurement / reproducibility knob for mava_ppo_critic_grad_f32 (default 1).  With a centralised critic the
- * reference tiles one global state to all A agents (mava/wrappers/jumanji.py:57-58) and evaluates the critic on
- * A identical rows; when x_share == A (<= 8) the kernel evaluates each (t,e) row once and back-propagates the sum
- * of its agents' loss gradients - mathematically the same gradient.  0 restores one pass per agent row. */
-int mava_ppo_set_critic_aggregation(int on);
-
-/* Arithmetic of mava_ppo_actor_grad_f32 / mava_ppo_critic_grad_f32 (process-wide).  0 (default): exact-f32 MFMA.
- * 1: "f16x2" - every matrix operand split into two f16 terms (hi + lo, ~22 mantissa bits), three f16 MFMAs per product
- * with f32 accumulation: 5.3x less matrix-pipe time, same 1e-4 gradient parity against the float64 oracle; applies to
- * the shapes mava_amd/csrc/ppo_train_h2.hip instantiates, other shapes keep running the exact-f32 kernel. */
-int mava_ppo_set_matmul_mode(int mode);
-int mava_ppo_get_matmul_mode(void);
+/* Both gradient kernels read MAVA_CTX_MATMUL_MODE, the critic also MAVA_CTX_CRITIC_AGGREGATION, from their handle. */
 
 /* ---- synthetic RWARE-shaped environment (measurement stand-in for the third-party Jumanji
  *      RobotWarehouse stepped at mava/systems/ppo/ff_mappo.py:88).  Wrapper semantics follow
@@ -196,7 +208,7 @@ int mava_synth_rware_step(int E, int A, int O, int n_actions, int gs_tiles, int 
  *      are independent, the parameters fixed), weights register-resident, observations handed from the env phase to
  *      the next acting step through LDS.  Same Philox streams as mava_policy_step_f32 (seed policy_seed, counter
  *      (row_offset + row, t0 + t, ., "POLI")) and mava_synth_rware_step (seed env_seed, step t0 + t + 1): bit-identical
- *      observations / masks / rewards / dones / metrics; networks in split-f16 arithmetic (see mava_ppo_set_matmul_mode).
+ *      observations / masks / rewards / dones / metrics; networks in split-f16 arithmetic (see MAVA_CTX_MATMUL_MODE).
  *      critic_shared 1: centralised critic on global_state (T+1, E, A*O), one value per env broadcast to its agents;
  *      0: decentralised critic on agents_view (global_state unused).  Slot 0 of agents_view / global_state /
  *      action_mask must hold the current observation; slots 1..T are written, the env state is advanced in place.
@@ -223,18 +235,18 @@ int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* c
 /* Y = act(X W + b) [masked by gate > 0]; X is T32 (x_ld >= K features per 32-row tile, the first K used; x_ld <= 0
  * means K) or, with x_rowmajor, the external row-major source (row stride x_ld >= K, so a call can read a column
  * block) gathered per batch row; W (K x N) row-major with row stride ldw; Y T32 (rows x N).  accumulate: start from
- * the existing Y (K-chunked products for inputs wider than 384).  With mava_ppo_set_matmul_mode(1) T32 inputs run on
+ * the existing Y (K-chunked products for inputs wider than 384).  With MAVA_CTX_MATMUL_MODE = 1 T32 inputs run on
  * split-f16 operands (rec_dense_h2.hip: 3 f16 MFMAs per product, f32 accumulate, operands must sit in f16 range -
  * see grad_scale below); row-major inputs always run the exact-f32 kernel.  y_ld (<= 0: N) is the feature count of the
  * y / gate tiles: a call with a column block of W and y + 32 * n0 writes features [n0, n0 + N) of a wider matrix. */
-int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+int mava_rec_dense_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                        int x_share, int x_ld, int accumulate, const float* w, int ldw, const float* bias,
                        const float* gate, float* y, int y_ld, int K, int N, int rows, int relu, mava_stream_t s);
 
 /* per-block slabs of out_scale * dW = X^T Y (K x N row-major) followed by out_scale * db = colsum(Y) when want_bias;
  * y_ld (<= 0: N) = features per y tile (y + 32 * n0 reads a column block of a wider matrix).
  * out_scale undoes the grad_scale the backward chain was started with (1.0f when none). */
-int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+int mava_rec_xty_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                      int x_share, int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
                      float* slab, long slab_stride, int n_slab, mava_stream_t s);
 /* Row-major, env-permuted observation slice of a minibatch (same gather description as mava_rec_dense_f32 with
@@ -242,20 +254,17 @@ int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm,
  * the pre-torso product and by its weight-gradient product as a plain T32 operand. */
 int mava_rec_gather_t32_f32(const float* x, const int32_t* idx, int Rm, int E, int A, int x_share, int x_ld, int K,
                             int rows, int k_pad, float* out, mava_stream_t s);
-/* 0 (default): exact-f32 MFMAs; 1: X^T Y on six bf16 MFMAs per f32 product (operands split hi/mid/lo once while they are
- * staged; f32 accuracy, parity-tested; currently slower - see rec_dense.hip).  For A/B measurements. */
-int mava_rec_xty_set_variant(int v);
 
 /* GRU over T steps (flax GRUCell; hidden state zeroed where done enters the step).  gi = W_i x + b_i
  * precomputed (T32, T*Rm x 384); wh (128 x 384) = [hr|hz|hn]; outputs hs (T32, h after each step) and,
  * for training, hprev (masked h entering each step) and saved (T*Rm x 512 = [r|z|n|W_hn h + b_hn]). */
-int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+int mava_gru_scan_fwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                           const float* h0, int h0_t32, const float* wh, const float* bhn,
                           const float* gi, float* hs, float* hprev, float* saved, mava_stream_t s);
 
 /* BPTT through the same scan: dh_out (T32) is the gradient reaching each h_t from the output path;
  * writes dgi and dgh (T32, T*Rm x 384: gradients w.r.t. the input-side and hidden-side gate pre-activations). */
-int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+int mava_gru_scan_bwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                           const float* wh, const float* saved, const float* hprev, const float* dh_out,
                           float* dgi, float* dgh, mava_stream_t s);
 

@@ -33,42 +33,40 @@ lng = C.c_long
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGNATURES = {
     "mava_abi_version": [],
-    "mava_gae_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
+    "mava_ctx_create": [vp],
+    "mava_ctx_destroy": [vp],
+    "mava_ctx_set": [vp, i32, lng],
+    "mava_ctx_get": [vp, i32, vp],
+    "mava_gae_f32": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp],
     "mava_permutation_i32": [lng, u64, u64, vp, vp],
-    "mava_gae_set_variant": [i32],
-    "mava_ppo_set_critic_aggregation": [i32],
-    "mava_ppo_set_matmul_mode": [i32],
-    "mava_ppo_get_matmul_mode": [],
-    "mava_policy_set_variant": [i32],
     "mava_clip_adam": [vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, f32, f32, i32, i32, i32,
                        f32, f32, f32, vp, f32, f32, vp, vp],
     "mava_slab_reduce_f32": [vp, i32, lng, i32, i32, vp, vp],
     "mava_slab_reduce2_f32": [vp, i32, lng, i32, vp, i32, vp, i32, vp],
     "mava_mlp_param_count": [i32, i32],
-    "mava_mlp_forward_f32": [vp, i32, i32, vp, i32, i32, vp, vp],
-    "mava_policy_step_f32": [vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
+    "mava_mlp_forward_f32": [vp, vp, i32, i32, vp, i32, i32, vp, vp],
+    "mava_policy_step_f32": [vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
                              vp, vp, vp, vp, vp, vp],
-    "mava_policy_step_continuous_f32": [vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
+    "mava_policy_step_continuous_f32": [vp, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
                                         vp, vp, vp, vp, vp, vp],
     "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32,
                                            u32, vp, lng, i32, vp],
     "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
                                            u32, f32, vp, vp, vp, vp, i32, vp],
     "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, vp, u64, u32, u32, i32, vp, vp, vp],
-    "mava_rec_xty_set_variant": [i32],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
     "mava_adv_stats_batched_f64": [vp, vp, lng, i32, i32, i32, vp, vp],
-    "mava_ppo_actor_grad_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
+    "mava_ppo_actor_grad_f32": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32,
                                 vp],
-    "mava_ppo_critic_grad_f32": [vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
+    "mava_ppo_critic_grad_f32": [vp, vp, i32, vp, i32, vp, vp, vp, lng, i32, i32, f32, f32, vp, lng, i32, vp],
     "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 14 + [vp, i32, vp],
     "mava_rollout_ff_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, u64, u64, u32, u32, u32, i32] + [vp] * 18 + [vp, vp, f32, f32, vp],
-    "mava_rec_dense_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mava_rec_xty_f32": [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
+    "mava_rec_dense_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mava_rec_xty_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
     "mava_rec_gather_t32_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
-    "mava_gru_scan_fwd_f32": [i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
-    "mava_gru_scan_bwd_f32": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mava_gru_scan_fwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "mava_gru_scan_bwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32,
                                      vp, vp, i32, i32, vp, vp],
@@ -118,6 +116,55 @@ def lib() -> C.CDLL:
             fn.argtypes = args
             fn.restype = C.c_int
     return _lib
+
+
+class Ctx:
+    """Context handle of the C ABI (include/mava_hip.h, mava_ctx_*): the arithmetic mode, the critic aggregation, the
+    bench-only kernel variants and the library-owned workspaces of ONE learner.  The library has no process-wide
+    settings: two Ctx objects (two learners in one process) share nothing.  `handle` is what the entry points take as
+    their first argument (None = the library defaults: exact f32)."""
+
+    MATMUL_MODE, CRITIC_AGGREGATION, GAE_VARIANT, POLICY_VARIANT, H2_LAUNCHES = 0, 1, 2, 3, 4
+
+    def __init__(self, matmul_mode: str = "f32", critic_aggregation: bool = True):
+        if matmul_mode not in ("f32", "f16x2"):
+            raise ValueError(f"matmul_mode must be 'f16x2' or 'f32', got {matmul_mode!r}")
+        h = C.c_void_p()
+        check(lib().mava_ctx_create(C.byref(h)), "mava_ctx_create")
+        self.handle: Optional[int] = h.value
+        self.set(self.MATMUL_MODE, 1 if matmul_mode == "f16x2" else 0)
+        self.set(self.CRITIC_AGGREGATION, int(bool(critic_aggregation)))
+
+    def set(self, key: int, value: int) -> None:
+        check(lib().mava_ctx_set(self.handle, key, int(value)), "mava_ctx_set")
+
+    def get(self, key: int) -> int:
+        out = C.c_long()
+        check(lib().mava_ctx_get(self.handle, key, C.byref(out)), "mava_ctx_get")
+        return int(out.value)
+
+    @property
+    def matmul_mode(self) -> str:
+        return "f16x2" if self.get(self.MATMUL_MODE) == 1 else "f32"
+
+    @property
+    def h2_launches(self) -> int:
+        return self.get(self.H2_LAUNCHES)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) is not None and _lib is not None:
+            _lib.mava_ctx_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ctx_ptr(ctx: Optional["Ctx"]) -> Optional[int]:
+    return None if ctx is None else ctx.handle
 
 
 def check(rc: int, what: str) -> None:

@@ -21,6 +21,7 @@
 // after ONE barrier composes the later chunks' pairs (<= NC-1 FMAs) to get its true A_in and
 // fixes up A_t = S_t + P_t * A_in from registers.
 #include "common.h"
+#include "ctx.h"
 
 namespace {
 
@@ -356,15 +357,7 @@ int launch_gae(const float* reward, const float* value, const uint8_t* done, con
 
 }  // namespace
 
-// Tuning knob exposed for bench sweeps: 0 = default.
-static int g_gae_variant = 0;
-
-extern "C" int mava_gae_set_variant(int variant) {
-  g_gae_variant = variant;
-  return MAVA_OK;
-}
-
-extern "C" int mava_gae_f32(const float* reward, const float* value, const uint8_t* done,
+extern "C" int mava_gae_f32(const mava_ctx* ctx, const float* reward, const float* value, const uint8_t* done,
                             const float* last_val, const uint8_t* last_done, int T, int N,
                             float gamma, float lambda, float* adv, float* tgt, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 0 && N >= 0, 0, "mava_gae_f32: negative shape T=%d N=%d", T, N);
@@ -374,7 +367,7 @@ extern "C" int mava_gae_f32(const float* reward, const float* value, const uint8
 #define GAE_ARGS reward, value, done, last_val, last_done, T, N, gamma, lambda, adv, tgt, s
   // columns must stay VEC-aligned in every time row
   const int align = (N % 4 == 0) ? 4 : ((N % 2 == 0) ? 2 : 1);
-  int variant = g_gae_variant;
+  int variant = mava_ctx_gae_variant(ctx);  // tuning knob of bench sweeps (tools/gae_sweep.py), 0 = default
   if (variant == 0) {
     // default (tools/gae_sweep.py on MI355X, graph-timed): scalar columns in 32-column strips (one 128-byte
     // line per time row), 8 chunks of 16 steps - 10.4 us from HBM / 7.2 us from cache at (128, 16384),

@@ -12,6 +12,7 @@
 // the critic, so one launch covers 2 * ceil(R/32) wave-tiles (1024 at the BASELINE config-2
 // shape: one per SIMD).  W2/W3/biases are staged in LDS once per block.
 #include "mlp_coop_body.h"
+#include "ctx.h"
 #include "tanh_normal.h"
 
 namespace {
@@ -280,22 +281,18 @@ int mava_coop_raw(const float* params, int din, int n_out, const float* x, int x
 // critic blocks, policy_hybrid_kernel) when the critic has at most 128 tiles; 1: per-wave kernel always;
 // 2: block-cooperative kernels, one launch per network (they pay a per-launch W2 staging cost that two 32-row
 // tiles per block cannot amortise: 49.6 vs 43.9 us per step at 16384 rows per network on MI355X)
-static int g_policy_variant = 0;
-extern "C" int mava_policy_set_variant(int v) {
-  g_policy_variant = v;
-  return MAVA_OK;
-}
+// (the variant is a field of the context handle: mava_ctx_set(ctx, MAVA_CTX_POLICY_VARIANT, v); NULL handle = 0)
 
 extern "C" int mava_mlp_param_count(int din, int n_out) { return mlp_param_count(din, n_out); }
 
-extern "C" int mava_mlp_forward_f32(const float* params, int din, int n_out, const float* x,
+extern "C" int mava_mlp_forward_f32(const mava_ctx* ctx, const float* params, int din, int n_out, const float* x,
                                     int x_share, int rows, float* out, hipStream_t s) {
   MAVA_ARG_CHECK(din >= 1 && n_out >= 1 && n_out <= 32, 0,
                  "mava_mlp_forward_f32: din=%d n_out=%d unsupported (n_out <= 32)", din, n_out);
   MAVA_ARG_CHECK(rows >= 0 && x_share >= 1, 1, "mava_mlp_forward_f32: rows=%d x_share=%d", rows, x_share);
   if (rows == 0) return MAVA_OK;
   MAVA_ARG_CHECK(params && x && out, 2, "mava_mlp_forward_f32: null pointer argument");
-  if (g_policy_variant == 2 && din <= 288) return mava_coop_raw(params, din, n_out, x, x_share, rows, out, s);
+  if (mava_ctx_policy_variant(ctx) == 2 && din <= 288) return mava_coop_raw(params, din, n_out, x, x_share, rows, out, s);
   FwdTask tk = {params, x, din, n_out, x_share, pick_xv(x, din), rows};
   const int ntiles = mava_cdiv(rows, 32);
   int blocks = mava_cdiv(ntiles, 4);
@@ -322,7 +319,7 @@ extern "C" int mava_mlp_forward_f32(const float* params, int din, int n_out, con
 }
 
 // Both acting entry points; action_f != nullptr selects the continuous head (action / forced_action unused then).
-static int policy_step_impl(const float* actor_params, int actor_din, int n_actions,
+static int policy_step_impl(int variant, const float* actor_params, int actor_din, int n_actions,
                             const float* agents_view, const uint8_t* action_mask,
                             const float* critic_params, int critic_din,
                             const float* critic_input, int critic_share, int critic_rows,
@@ -340,7 +337,7 @@ static int policy_step_impl(const float* actor_params, int actor_din, int n_acti
                  "mava_policy_step_f32: null actor pointer argument");
   MAVA_ARG_CHECK(critic_rows == 0 || (critic_params && critic_input && value), 2,
                  "mava_policy_step_f32: null critic pointer argument");
-  if (g_policy_variant == 2 && actor_din <= 288 && critic_din <= 288 && action_f == nullptr) {
+  if (variant == 2 && actor_din <= 288 && critic_din <= 288 && action_f == nullptr) {
     int rc = MAVA_OK;
     if (rows > 0)
       rc = mava_coop_actor(actor_params, actor_din, n_actions, agents_view, action_mask, rows, seed, step, step_base, row_offset,
@@ -359,7 +356,7 @@ static int policy_step_impl(const float* actor_params, int actor_din, int n_acti
     const int tiles_c = mava_cdiv(critic_rows, 32);
     int nba_h = mava_cdiv(mava_cdiv(rows, 32), 4);
     if (nba_h > 128) nba_h = 128;
-    if (g_policy_variant == 0 && rows > 0 && critic_rows > 0 && tiles_c <= 128 && critic_din <= 287) {
+    if (variant == 0 && rows > 0 && critic_rows > 0 && tiles_c <= 128 && critic_din <= 287) {
       coop::CoopTask ck = {};
       ck.params = critic_params; ck.x = critic_input; ck.din = critic_din; ck.no = 1; ck.xshare = critic_share;
       ck.R = critic_rows; ck.value = value; ck.vbroadcast = value_broadcast;
@@ -395,7 +392,7 @@ static int policy_step_impl(const float* actor_params, int actor_din, int n_acti
   return MAVA_OK;
 }
 
-extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, int n_actions,
+extern "C" int mava_policy_step_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int n_actions,
                                     const float* agents_view, const uint8_t* action_mask,
                                     const float* critic_params, int critic_din,
                                     const float* critic_input, int critic_share, int critic_rows,
@@ -403,12 +400,12 @@ extern "C" int mava_policy_step_f32(const float* actor_params, int actor_din, in
                                     uint32_t row_offset, int greedy, const int32_t* forced_action,
                                     int32_t* action, float* log_prob, float* value, float* logits,
                                     hipStream_t s) {
-  return policy_step_impl(actor_params, actor_din, n_actions, agents_view, action_mask, critic_params, critic_din,
+  return policy_step_impl(mava_ctx_policy_variant(ctx), actor_params, actor_din, n_actions, agents_view, action_mask, critic_params, critic_din,
                           critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
                           row_offset, greedy, forced_action, action, log_prob, value, logits, nullptr, nullptr, s);
 }
 
-extern "C" int mava_policy_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+extern "C" int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int action_dim,
                                                const float* agents_view, const float* critic_params, int critic_din,
                                                const float* critic_input, int critic_share, int critic_rows,
                                                int value_broadcast, int rows, uint64_t seed, uint32_t step,
@@ -416,7 +413,7 @@ extern "C" int mava_policy_step_continuous_f32(const float* actor_params, int ac
                                                const float* forced_action, float* action, float* log_prob,
                                                float* value, float* mean, hipStream_t s) {
   MAVA_ARG_CHECK(rows == 0 || action != nullptr, 2, "mava_policy_step_continuous_f32: null action pointer");
-  return policy_step_impl(actor_params, actor_din, action_dim, agents_view, nullptr, critic_params, critic_din,
+  return policy_step_impl(mava_ctx_policy_variant(ctx), actor_params, actor_din, action_dim, agents_view, nullptr, critic_params, critic_din,
                           critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
                           row_offset, greedy, nullptr, nullptr, log_prob, value, mean, action, forced_action, s);
 }

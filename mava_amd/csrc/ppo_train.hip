@@ -29,6 +29,7 @@
 // gradient is bitwise reproducible (no float atomics).
 #include "mlp_core.h"
 #include "ppo_train_task.h"
+#include "ctx.h"
 #include "tanh_normal.h"
 
 namespace {
@@ -177,36 +178,6 @@ __device__ __forceinline__ float group_allreduce(float v, Op op) {
   if (G >= 32) v = op(v, __shfl_xor(v, 16, 64));
   return v;
 }
-
-// f32 operand -> three bf16 terms (hi + mid + lo, round to nearest): the six products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
-// lo*hi on v_mfma_f32_32x32x16_bf16 (f32 accumulation, bf16 x bf16 exact) reproduce the f32 product to f32 accuracy
-// (tools/bf16_split_study.py, tools/microbench/bf16x6_mfma.hip) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 inputs.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)x[i];
-    const float r1 = x[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    hi[i] = h; mid[i] = m; lo[i] = (__bf16)(r1 - (float)m);
-  }
-}
-__device__ __forceinline__ f32x16 mfma_bf16x6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
-                                              const bf16x8& bm, const bf16x8& bl, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);  // small terms first
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-}
-// Pilot (off by default, -DMAVA_GW2_BF16X6=1 through MAVA_HIPCC_EXTRA): the gW2 product of P5 on this form.  Parity holds
-// (every gradient test passes), but each wave has to split all 128 features of h1^T itself - 4x redundant VALU work that the
-// 48 bf16 MFMAs do not cover: actor 1.59 vs 1.51 ms, critic 0.62 vs 0.59 ms per launch.  The form pays once every consumer of
-// an exchange tile reads it pre-split (the producer splits once), which is a new LDS layout for the whole kernel - DESIGN §9.
-#ifndef MAVA_GW2_BF16X6
-#define MAVA_GW2_BF16X6 0
-#endif
 
 template <int NO, int KT1, bool ACTOR, int XV, bool CONT>
 __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLdsLayout L) {
@@ -787,34 +758,6 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
     // ---------------------------------------------------------------- P5: weight gradients
     // gW2 needs h1^T and dz2^T only, so it runs BEFORE barrier D: the dz1^T writes above drain under its MFMAs
     // instead of in front of the barrier
-#if MAVA_GW2_BF16X6
-    {
-      // gW2[k_in tile t][n = 32w + j] += sum_rows h1^T[k_in][row] * dz2^T[n][row] as bf16 x 6: MFMA m of a 32-row tile
-      // multiplies rows 16m + 8h + s (lane half h, slot s) - eight consecutive floats of a [feature][row] exchange row
-      const float* ea = H1T + j * LDT + 8 * h;
-      const float* eb = DZ2T + (32 * w + j) * LDT + 8 * h;
-      bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float v[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = eb[16 * m + s];
-        split3(v, bh[m], bm[m], bl[m]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          float v[8];
-#pragma unroll
-          for (int s = 0; s < 8; ++s) v[s] = ea[(32 * t) * LDT + 16 * m + s];
-          bf16x8 ah, am, al;
-          split3(v, ah, am, al);
-          gW2[t] = mfma_bf16x6(ah, am, al, bh[m], bm[m], bl[m], gW2[t]);
-        }
-      }
-    }
-#else
     {
       // gW2[k_in tile t][n = 32w + j] += sum_rows h1^T[k_in][row] * dz2^T[n][row]
       const float* ea = H1T + j * LDT + h;
@@ -829,7 +772,6 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#endif
     STAMP(5);
     __syncthreads();  // D: dz1^T complete
     {
@@ -1001,33 +943,25 @@ int dispatch_kt(const TrainTask& tk, int n_slab, hipStream_t s) {
 
 }  // namespace
 
+#ifdef MAVA_STAMPS
+// Diagnostic builds only (-DMAVA_STAMPS, tools/build_stamps.sh; not part of include/mava_hip.h): device buffer of 40 u64
+// receiving block 0's per-phase cycle sums.
 static unsigned long long* g_stamps = nullptr;
-// Diagnostic hook (not part of include/mava_hip.h): device buffer of 40 u64 receiving block 0's per-phase
-// cycle sums when the library is built with -DMAVA_STAMPS; ignored otherwise.
 extern "C" int mava_debug_set_stamps(unsigned long long* p) {
   g_stamps = p;
   return MAVA_OK;
 }
+#else
+static constexpr unsigned long long* g_stamps = nullptr;
+#endif
 
-static int g_critic_agg = 1;
-// 1 (default): when the A agents of a (t,e) row share one critic input row (x_share == A <= 8) the critic kernel
-// evaluates the network once per row and back-propagates the sum of the agents' loss gradients - the same gradient
-// as A identical passes, at 1/A of the matrix work.  0: one pass per agent row (the reference's arithmetic order).
-extern "C" int mava_ppo_set_critic_aggregation(int on) {
-  g_critic_agg = on ? 1 : 0;
-  return MAVA_OK;
-}
-
-static int g_matmul_mode = 0;
-// Arithmetic of the fused PPO gradient kernels.  0: exact-f32 MFMA (v_mfma_f32_32x32x2_f32, ppo_train.hip);
-// 1: split-f16 operands, three v_mfma_f32_32x32x16_f16 per product, f32 accumulation (ppo_train_h2.hip) - used for the
-// shapes that kernel instantiates (discrete actor / critic, input width <= 95), everything else stays on mode 0.
-extern "C" int mava_ppo_set_matmul_mode(int mode) {
-  MAVA_ARG_CHECK(mode == 0 || mode == 1, 0, "mava_ppo_set_matmul_mode: mode %d (0 = exact f32, 1 = f16x2)", mode);
-  g_matmul_mode = mode;
-  return MAVA_OK;
-}
-extern "C" int mava_ppo_get_matmul_mode(void) { return g_matmul_mode; }
+// Settings of these kernels live in the caller's context handle (ctx.h; NULL = defaults):
+//   critic aggregation, 1 (default): when the A agents of a (t,e) row share one critic input row (x_share == A <= 8) the
+//     critic kernel evaluates the network once per row and back-propagates the sum of the agents' loss gradients - the
+//     same gradient as A identical passes, at 1/A of the matrix work.  0: one pass per agent row (the reference's order).
+//   matmul mode, 0: exact-f32 MFMA (v_mfma_f32_32x32x2_f32, this file); 1: split-f16 operands, three
+//     v_mfma_f32_32x32x16_f16 per product, f32 accumulation (ppo_train_h2.hip) for the shapes that kernel instantiates
+//     (discrete actor / critic, input width <= 287); everything else stays on mode 0.
 
 extern "C" int mava_adv_stats_blocks(void) { return STATS_BLOCKS; }
 
@@ -1055,7 +989,7 @@ extern "C" int mava_adv_stats_batched_f64(const float* adv, const int32_t* idx, 
   return MAVA_OK;
 }
 
-extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actions,
+extern "C" int mava_ppo_actor_grad_f32(mava_ctx* ctx, const float* params, int din, int n_actions,
                                        const float* agents_view, const uint8_t* action_mask,
                                        const int32_t* action, const float* old_log_prob,
                                        const float* advantages, const double* adv_stats,
@@ -1077,8 +1011,8 @@ extern "C" int mava_ppo_actor_grad_f32(const float* params, int din, int n_actio
   tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
   tk.slab_stride = slab_stride;
   tk.stamps = g_stamps;
-  if (g_matmul_mode == 1) {
-    const int rc = mava_train_h2_launch(tk, n_slab, true, s);
+  if (mava_ctx_matmul_mode(ctx) == 1) {
+    const int rc = mava_train_h2_launch(ctx, tk, n_slab, true, s);
     if (rc <= 0) return rc;  // launched (0) or failed (< 0); 1: shape not instantiated there
   }
   if (n_actions <= 8) return dispatch_kt<8, true>(tk, n_slab, s);
@@ -1117,7 +1051,7 @@ extern "C" int mava_ppo_actor_grad_continuous_f32(const float* params, int din, 
   return dispatch_kt<16, true, true>(tk, n_slab, s);
 }
 
-extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const float* critic_input,
+extern "C" int mava_ppo_critic_grad_f32(mava_ctx* ctx, const float* params, int din, const float* critic_input,
                                         int x_share, const float* old_value, const float* targets,
                                         const int32_t* idx, long idx_base, int Rb, int A,
                                         float clip_eps, float vf_coef, float* slab, long slab_stride,
@@ -1131,7 +1065,7 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
                  "mava_ppo_critic_grad_f32: null pointer argument");
   TrainTask tk = {};
   tk.params = params; tk.x = critic_input; tk.din = din; tk.no = 1; tk.xshare = x_share; tk.agg = 1;
-  if (g_critic_agg && A > 1 && A <= 8 && x_share == A) {  // input row of index p is row p itself
+  if (mava_ctx_critic_aggregation(ctx) && A > 1 && A <= 8 && x_share == A) {  // input row of index p is row p itself
     tk.agg = A;
     tk.xshare = 1;
   }
@@ -1139,8 +1073,8 @@ extern "C" int mava_ppo_critic_grad_f32(const float* params, int din, const floa
   tk.old_value = old_value; tk.targets = targets; tk.clip_eps = clip_eps; tk.vf_coef = vf_coef;
   tk.slab = slab; tk.slab_stride = slab_stride;
   tk.stamps = g_stamps;
-  if (g_matmul_mode == 1) {
-    const int rc = mava_train_h2_launch(tk, n_slab, false, s);
+  if (mava_ctx_matmul_mode(ctx) == 1) {
+    const int rc = mava_train_h2_launch(ctx, tk, n_slab, false, s);
     if (rc <= 0) return rc;
   }
   return dispatch_kt<1, false>(tk, n_slab, s);

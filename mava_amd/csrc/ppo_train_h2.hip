@@ -28,6 +28,7 @@
 //   * the x tile is double-buffered in LDS, which removes two of the seven barriers per tile.
 #include "h2_core.h"
 #include "ppo_train_task.h"
+#include "ctx.h"
 
 // Operand prefetch depth of the weight-gradient products (0 = pairs of reads followed by pairs of products).  A rolling
 // prefetch (operand of product i + depth read while product i runs) was measured at depth 3 (narrow kernels) and 2 / 3 (the
@@ -987,12 +988,11 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 2 : 1) void ppo_train_h2_k
   }
 }
 
-// WIDE launches: one pre-split copy of W1 per network kind, allocated on first use and kept for the process
-// (18 steps x 256 lanes x 32 bytes = 147 KB); filled by pack_w1_kernel on the launch stream ahead of every launch.
-uint4* g_w1p[2] = {nullptr, nullptr};
-
+// WIDE launches: one pre-split copy of W1 per network kind in the caller's context handle (ctx.h), allocated on first
+// use and freed by mava_ctx_destroy (18 steps x 256 lanes x 32 bytes = 147 KB); filled by pack_w1_kernel on the launch
+// stream ahead of every launch - launches that share a handle must therefore be on one stream.
 template <int NO, int S1, bool ACTOR, bool WIDE, int XV>
-int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
+int launch_h2(mava_ctx* ctx, const TrainTask& tk, int n_slab, hipStream_t s) {
   const H2Layout L = make_h2_layout<NO, S1, WIDE>(ACTOR);
   MAVA_ARG_CHECK(L.end <= 163840, 8, "ppo_train_h2: %d bytes of LDS exceed the 160 KiB of a CU", L.end);
   static bool attr_set = false;
@@ -1003,8 +1003,9 @@ int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
   }
   const uint4* w1p = nullptr;
   if (WIDE) {
-    uint4*& buf = g_w1p[ACTOR ? 0 : 1];
-    if (buf == nullptr) MAVA_HIP_CHECK(hipMalloc((void**)&buf, (size_t)18 * 256 * 32));
+    void*& slot = ctx->w1_split[ACTOR ? 0 : 1];
+    if (slot == nullptr) MAVA_HIP_CHECK(hipMalloc(&slot, (size_t)18 * 256 * 32));
+    uint4* const buf = static_cast<uint4*>(slot);
     hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf);
     MAVA_LAUNCH_CHECK();
     w1p = buf;
@@ -1016,58 +1017,56 @@ int launch_h2(const TrainTask& tk, int n_slab, hipStream_t s) {
 }
 
 template <int NO, int S1, bool ACTOR, bool WIDE>
-int dispatch_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
+int dispatch_xv(mava_ctx* ctx, const TrainTask& tk, int n_slab, hipStream_t s) {
   const uintptr_t a = (uintptr_t)tk.x;
   if constexpr (WIDE) {
-    if (tk.din % 4 == 0 && a % 16 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 4>(tk, n_slab, s);
+    if (tk.din % 4 == 0 && a % 16 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 4>(ctx, tk, n_slab, s);
   } else {
-    if (tk.din % 2 == 0 && a % 8 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 2>(tk, n_slab, s);
+    if (tk.din % 2 == 0 && a % 8 == 0) return launch_h2<NO, S1, ACTOR, WIDE, 2>(ctx, tk, n_slab, s);
   }
-  return launch_h2<NO, S1, ACTOR, WIDE, 1>(tk, n_slab, s);
+  return launch_h2<NO, S1, ACTOR, WIDE, 1>(ctx, tk, n_slab, s);
 }
 
 template <int NO, bool ACTOR>
-int dispatch_s1(const TrainTask& tk, int n_slab, hipStream_t s) {
+int dispatch_s1(mava_ctx* ctx, const TrainTask& tk, int n_slab, hipStream_t s) {
   const int s1 = (tk.din + 1 + 15) / 16;  // 16-input steps of layer 1, including the ones (bias) column
   switch (s1) {
 #ifndef MAVA_FAST_BUILD
-    case 1: return dispatch_xv<NO, 1, ACTOR, false>(tk, n_slab, s);
-    case 2: return dispatch_xv<NO, 2, ACTOR, false>(tk, n_slab, s);
-    case 3: return dispatch_xv<NO, 3, ACTOR, false>(tk, n_slab, s);
-    case 4: return dispatch_xv<NO, 4, ACTOR, false>(tk, n_slab, s);
-    case 6: return dispatch_xv<NO, 6, ACTOR, false>(tk, n_slab, s);
-    case 7: case 8: case 9: case 10: case 11: case 12: return dispatch_xv<NO, 12, ACTOR, true>(tk, n_slab, s);
+    case 1: return dispatch_xv<NO, 1, ACTOR, false>(ctx, tk, n_slab, s);
+    case 2: return dispatch_xv<NO, 2, ACTOR, false>(ctx, tk, n_slab, s);
+    case 3: return dispatch_xv<NO, 3, ACTOR, false>(ctx, tk, n_slab, s);
+    case 4: return dispatch_xv<NO, 4, ACTOR, false>(ctx, tk, n_slab, s);
+    case 6: return dispatch_xv<NO, 6, ACTOR, false>(ctx, tk, n_slab, s);
+    case 7: case 8: case 9: case 10: case 11: case 12: return dispatch_xv<NO, 12, ACTOR, true>(ctx, tk, n_slab, s);
 #endif
     // (the role-split 512-thread form was also measured for this narrow input: actor 0.94 instead of 0.70 ms per launch -
     // the resident W1 fragments and one barrier set per tile beat the second wave group here)
-    case 5: return dispatch_xv<NO, 5, ACTOR, false>(tk, n_slab, s);
-    case 13: case 14: case 15: case 16: case 17: case 18: return dispatch_xv<NO, 18, ACTOR, true>(tk, n_slab, s);
+    case 5: return dispatch_xv<NO, 5, ACTOR, false>(ctx, tk, n_slab, s);
+    case 13: case 14: case 15: case 16: case 17: case 18: return dispatch_xv<NO, 18, ACTOR, true>(ctx, tk, n_slab, s);
     default: return 1;  // not instantiated (input width > 287): the caller runs the exact-f32 kernel
   }
 }
 
 }  // namespace
 
-static long g_h2_launches = 0;
-// Diagnostic (not part of include/mava_hip.h): launches that really ran on the split-f16 kernel.
-extern "C" long mava_debug_h2_launches(void) { return g_h2_launches; }
-
-static int h2_dispatch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
+static int h2_dispatch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
   if (actor) {
     if (tk.action_f != nullptr) return 1;  // continuous head: exact-f32 kernel
-    if (tk.no <= 8) return dispatch_s1<8, true>(tk, n_slab, s);
+    if (tk.no <= 8) return dispatch_s1<8, true>(ctx, tk, n_slab, s);
 #ifndef MAVA_FAST_BUILD
-    if (tk.no <= 16) return dispatch_s1<16, true>(tk, n_slab, s);
-    return dispatch_s1<32, true>(tk, n_slab, s);
+    if (tk.no <= 16) return dispatch_s1<16, true>(ctx, tk, n_slab, s);
+    return dispatch_s1<32, true>(ctx, tk, n_slab, s);
 #else
     return 1;
 #endif
   }
-  return dispatch_s1<1, false>(tk, n_slab, s);
+  return dispatch_s1<1, false>(ctx, tk, n_slab, s);
 }
 
-int mava_train_h2_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
-  const int rc = h2_dispatch(tk, n_slab, actor, s);
-  if (rc == 0) ++g_h2_launches;
+// (ctx is never NULL here: a NULL handle means exact f32 and does not reach this file.)  h2_launches counts the launches
+// that really ran on the split-f16 kernel (mava_ctx_get(ctx, MAVA_CTX_H2_LAUNCHES): the parity tests assert it).
+int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
+  const int rc = h2_dispatch(ctx, tk, n_slab, actor, s);
+  if (rc == 0) ++ctx->h2_launches;
   return rc;
 }

@@ -33,4 +33,5 @@ struct TrainTask {
 // ppo_train_h2.hip: the same fused kernel on v_mfma_f32_32x32x16_f16 with every operand split into two f16 terms
 // (hi + lo, f32 accumulation).  Returns MAVA_OK, or 1 when the shape is not instantiated (the caller then runs the
 // exact-f32 kernel), or a negative error code.
-int mava_train_h2_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s);
+struct mava_ctx;
+int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s);

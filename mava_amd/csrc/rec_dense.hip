@@ -16,7 +16,7 @@
 #include "mlp_core.h"
 #include "rec_task.h"
 
-extern "C" int mava_ppo_get_matmul_mode(void);
+#include "ctx.h"
 
 namespace {
 
@@ -423,191 +423,6 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
   }
 }
 
-// ---- X^T Y on the matrix pipe's bf16 rate at f32 accuracy ------------------------------------------------------------
-// Every f32 operand is split into three bf16 terms (hi + mid + lo) ONCE, by the thread that stages it into LDS; the six
-// products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi on v_mfma_f32_32x32x16_bf16 (exact bf16 products, f32 accumulation)
-// reproduce the f32 product to f32 accuracy at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 rows
-// (tools/bf16_split_study.py, tools/microbench/bf16x6_mfma.hip: 1.9-2.1x the f32 MFMA rate, same error against float64).
-// LDS tiles are [term][feature][40] bf16: the 32 rows of a feature are contiguous (an operand of 8 consecutive rows is one
-// ds_read_b128) and a row of 80 bytes is an odd number of 16-byte slots (conflict-free across the 32 features of a wave).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int XRS = 40;  // bf16 elements per feature row
-
-__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-  hi = (__bf16)x;
-  const float r1 = x - (float)hi;
-  mid = (__bf16)r1;
-  lo = (__bf16)(r1 - (float)mid);
-}
-
-template <int KT, int NTW>
-__global__ __launch_bounds__(256, 1) void rec_xty_bf16x6_kernel(XtyTask tk) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
-  const int K = tk.K, N = tk.N;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
-  const int ntile_n = (N + 31) / 32;
-  const int npad = ntile_n * 32;
-  const int xterm = 32 * KT * XRS, yterm = npad * XRS;  // elements per term array
-  __bf16* const XT = ldsb;               // [3][32*KT][XRS]
-  __bf16* const YT = ldsb + 3 * xterm;   // [3][npad][XRS]
-
-  f32x16 acc[KT][NTW];
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[kt][tw][r] = 0.0f;
-
-  {  // features past K / N stay zero for the whole launch
-    uint32_t* z = reinterpret_cast<uint32_t*>(ldsb);
-    const int nz = 3 * (xterm + yterm) / 2;
-    for (int i = tid; i < nz; i += 256) z[i] = 0u;
-  }
-  __syncthreads();
-
-  constexpr int NT_ALL = 4 * NTW;
-  float4 xq[KT], yq[NT_ALL];
-  float bacc[NT_ALL];  // lanes with (tid & 7) == 0: column sum of feature (tid >> 3) + 32 i
-#pragma unroll
-  for (int i = 0; i < NT_ALL; ++i) bacc[i] = 0.0f;
-  const int nx4 = K * 8, ny4 = N * 8;  // float4 per tile
-  auto issue = [&](int it) {
-    const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * tk.y_ld) * 32);
-#pragma unroll
-    for (int i = 0; i < NT_ALL; ++i) {
-      const int q = tid + 256 * i;
-      yq[i] = ysrc[q < ny4 ? q : (ny4 - 1)];
-    }
-    if (!tk.x_rowmajor) {
-      const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * tk.x_ld) * 32);
-#pragma unroll
-      for (int i = 0; i < KT; ++i) {
-        const int q = tid + 256 * i;
-        xq[i] = xsrc[q < nx4 ? q : (nx4 - 1)];
-      }
-    }
-  };
-  // four consecutive rows of one feature -> three 8-byte stores
-  auto put4 = [&](__bf16* base, int term_stride, int f, int r, const float4& v) {
-    bf16x4 t0, t1, t2;
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      __bf16 a, b, d2;
-      split3(vv[c], a, b, d2);
-      t0[c] = a; t1[c] = b; t2[c] = d2;
-    }
-    __bf16* d = base + f * XRS + r;
-    *reinterpret_cast<bf16x4*>(d) = t0;
-    *reinterpret_cast<bf16x4*>(d + term_stride) = t1;
-    *reinterpret_cast<bf16x4*>(d + 2 * term_stride) = t2;
-  };
-  auto commit = [&](int it) {
-#pragma unroll
-    for (int i = 0; i < NT_ALL; ++i) {
-      const int q = tid + 256 * i;
-      const bool in = q < ny4;
-      if (in) {
-        const int e = 4 * q;
-        put4(YT, yterm, e >> 5, e & 31, yq[i]);
-      }
-      if (tk.want_bias) {
-        // the 8 threads tid & ~7 .. | 7 hold the 32 rows of feature q >> 3: fixed-order tree, then one accumulator
-        float s4 = in ? ((yq[i].x + yq[i].y) + (yq[i].z + yq[i].w)) : 0.0f;
-        s4 += __shfl_xor(s4, 1, 64);
-        s4 += __shfl_xor(s4, 2, 64);
-        s4 += __shfl_xor(s4, 4, 64);
-        bacc[i] += s4;
-      }
-    }
-    if (!tk.x_rowmajor) {
-#pragma unroll
-      for (int i = 0; i < KT; ++i) {
-        const int q = tid + 256 * i;
-        if (q < nx4) {
-          const int e = 4 * q;
-          put4(XT, xterm, e >> 5, e & 31, xq[i]);
-        }
-      }
-    } else {
-      const int srow = tid >> 3, l8 = tid & 7;
-      DenseTask g;
-      g.Rm = tk.Rm; g.E = tk.E; g.A = tk.A; g.xshare = tk.xshare; g.idx = tk.idx;
-      const float* xrow = tk.x + gather_row(g, it * 32 + srow) * tk.x_ld;
-      for (int k = l8; k < K; k += 8) {
-        __bf16 t0, t1, t2;
-        split3(xrow[k], t0, t1, t2);
-        __bf16* d = XT + k * XRS + srow;
-        d[0] = t0; d[xterm] = t1; d[2 * xterm] = t2;
-      }
-    }
-  };
-
-  const int ntiles = tk.rows / 32;
-  int it = blockIdx.x;
-  if (it < ntiles) {
-    issue(it);
-    commit(it);
-  }
-  __syncthreads();
-  for (; it < ntiles; it += gridDim.x) {
-    const int itn = it + gridDim.x;
-    if (itn < ntiles) issue(itn);
-    // ---- dW[k][n] += sum_rows x[row][k] * y[row][n]; MFMA m multiplies rows 16m + 8h + s (lane half h, slot s)
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw) {
-      if (w + 4 * tw < ntile_n) {
-        const __bf16* eb = YT + (32 * (w + 4 * tw) + j) * XRS + 8 * h;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(eb + 16 * m);
-          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(eb + 16 * m + yterm);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(eb + 16 * m + 2 * yterm);
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt) {
-            const __bf16* ea = XT + (32 * kt + j) * XRS + 8 * h + 16 * m;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ea);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ea + xterm);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ea + 2 * xterm);
-            // small terms first
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[kt][tw], 0, 0, 0);
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[kt][tw], 0, 0, 0);
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[kt][tw], 0, 0, 0);
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[kt][tw], 0, 0, 0);
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[kt][tw], 0, 0, 0);
-            acc[kt][tw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[kt][tw], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    __syncthreads();  // all readers of the staged tiles are done
-    if (itn < ntiles) commit(itn);
-    __syncthreads();
-  }
-  float* slab = tk.slab + (long)blockIdx.x * tk.slab_stride;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = 32 * (w + 4 * tw) + j;
-        if (k < K && n < N) slab[(long)k * N + n] = acc[kt][tw][r] * tk.out_scale;
-      }
-  if (tk.want_bias && (tid & 7) == 0) {
-#pragma unroll
-    for (int i = 0; i < NT_ALL; ++i) {
-      const int n = (tid >> 3) + 32 * i;
-      if (n < N) slab[(long)K * N + n] = bacc[i] * tk.out_scale;
-    }
-  }
-}
-
 template <int NB, int NTW, bool RM, bool FULLK>
 int launch_dense_rm(const DenseTask& tk, hipStream_t s) {
   const size_t lb = RM ? ((size_t)32 * (16 * NB + 1) + 4) * sizeof(float) : 0;
@@ -638,30 +453,9 @@ int launch_dense(const DenseTask& tk, hipStream_t s) {
   return MAVA_EARG(9);
 }
 
-// 0 (default): exact-f32 MFMAs; 1: the bf16 x 6 form above (mava_rec_xty_set_variant).  Measured at the rec_mappo
-// config-4 shapes (rocprofv3, per launch): <4,1> 259 vs 223 us, <4,3> 928 vs 725 us (111 spilled registers next to 192
-// accumulators), <6,1> row-major gather 858 vs 433 us (three 2-byte LDS stores per element).  Parity holds everywhere; the
-// matrix time does drop (48 instead of 64 x 2 issue slots per tile at <4,1>), but the splits sit in the commit phase between
-// the two barriers of a tile, where nothing overlaps them.  It needs a second LDS tile buffer so that the staging of tile
-// i+1 runs under the MFMAs of tile i (fits for N <= 128; N = 384 as three column passes) - DESIGN §9.
-int g_xty_variant = 0;
-
 template <int KT, int NTW>
 int launch_xty(const XtyTask& tk, int n_slab, hipStream_t s) {
   const int npad = ((tk.N + 31) / 32) * 32;
-  if (g_xty_variant == 1) {
-    const size_t lbb = (size_t)3 * (32 * KT + npad) * XRS * sizeof(__bf16);
-    MAVA_ARG_CHECK(lbb <= 163840, 8, "mava_rec_xty_f32: %zu bytes of LDS needed", lbb);
-    static bool attr_set_b = false;
-    if (!attr_set_b) {
-      MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rec_xty_bf16x6_kernel<KT, NTW>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-      attr_set_b = true;
-    }
-    hipLaunchKernelGGL((rec_xty_bf16x6_kernel<KT, NTW>), dim3(n_slab), dim3(256), lbb, s, tk);
-    MAVA_LAUNCH_CHECK();
-    return MAVA_OK;
-  }
   const size_t lb = (size_t)(32 * KT + npad) * 33 * sizeof(float);
   MAVA_ARG_CHECK(lb <= 163840, 8, "mava_rec_xty_f32: %zu bytes of LDS needed", lb);
   static bool attr_set = false;  // once per instantiation: allow the whole 160 KiB (lb varies with N)
@@ -677,12 +471,7 @@ int launch_xty(const XtyTask& tk, int n_slab, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mava_rec_xty_set_variant(int v) {
-  g_xty_variant = v ? 1 : 0;
-  return MAVA_OK;
-}
-
-extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
+extern "C" int mava_rec_dense_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
                                   int x_share, int x_ld, int accumulate, const float* w, int ldw,
                                   const float* bias, const float* gate, float* y, int y_ld, int K, int N, int rows,
                                   int relu, hipStream_t s) {
@@ -698,7 +487,7 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
   MAVA_ARG_CHECK(x_rowmajor || x_ld >= K, 5, "mava_rec_dense_f32: T32 input with %d features per tile < K=%d", x_ld, K);
   MAVA_ARG_CHECK(y_ld >= N, 7, "mava_rec_dense_f32: y_ld=%d < N=%d", y_ld, N);
   DenseTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, accumulate, w, ldw, bias, gate, y, K, N, rows, relu, y_ld};
-  if (mava_ppo_get_matmul_mode() == 1) {
+  if (mava_ctx_matmul_mode(ctx) == 1) {
     const int rc = mava_rec_dense_h2_launch(tk, s);
     if (rc <= 0) return rc;
   }
@@ -715,7 +504,7 @@ extern "C" int mava_rec_dense_f32(const float* x, int x_rowmajor, const int32_t*
   return MAVA_EARG(9);
 }
 
-extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
+extern "C" int mava_rec_xty_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
                                 int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
                                 float* slab, long slab_stride, int n_slab, hipStream_t s) {
   if (!x_rowmajor && x_ld <= 0) x_ld = K;
@@ -728,7 +517,7 @@ extern "C" int mava_rec_xty_f32(const float* x, int x_rowmajor, const int32_t* i
   MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
   MAVA_ARG_CHECK(x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
   XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, y_ld, slab, slab_stride, want_bias, out_scale};
-  if (mava_ppo_get_matmul_mode() == 1 && g_xty_variant == 0) {
+  if (mava_ctx_matmul_mode(ctx) == 1) {
     const int rc = mava_rec_xty_h2_launch(tk, n_slab, s);
     if (rc <= 0) return rc;
   }

@@ -16,7 +16,7 @@
 #include "rec_task.h"
 #include "tanh_normal.h"
 
-extern "C" int mava_ppo_get_matmul_mode(void);
+#include "ctx.h"
 
 namespace {
 
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void rows_to_t32_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+extern "C" int mava_gru_scan_fwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                                      const float* h0, int h0_t32, const float* wh, const float* bhn,
                                      const float* gi, float* hs, float* hprev, float* saved, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm >= 32 && Rm % 32 == 0 && E >= 1 && A >= 1 && Rm % A == 0, 0,
@@ -561,13 +561,13 @@ extern "C" int mava_gru_scan_fwd_f32(int T, int Rm, int E, int A, const int32_t*
   ScanTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.h0 = h0; tk.h0_t32 = h0_t32;
   tk.wh = wh; tk.bhn = bhn; tk.gi = gi; tk.hs = hs; tk.hprev = hprev; tk.saved = saved;
-  if (mava_ppo_get_matmul_mode() == 1) return mava_gru_scan_fwd_h2_launch(tk, s);  // rec_gru_h2.hip
+  if (mava_ctx_matmul_mode(ctx) == 1) return mava_gru_scan_fwd_h2_launch(tk, s);  // rec_gru_h2.hip
   hipLaunchKernelGGL(gru_scan_fwd_kernel, dim3(Rm / 32), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
 
-extern "C" int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
+extern "C" int mava_gru_scan_bwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                                      const float* wh, const float* saved, const float* hprev,
                                      const float* dh_out, float* dgi, float* dgh, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm >= 32 && Rm % 32 == 0 && E >= 1 && A >= 1 && Rm % A == 0, 0,
@@ -578,7 +578,7 @@ extern "C" int mava_gru_scan_bwd_f32(int T, int Rm, int E, int A, const int32_t*
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.wh = wh;
   tk.saved = const_cast<float*>(saved); tk.hprev = const_cast<float*>(hprev); tk.dh_out = dh_out;
   tk.dgi = dgi; tk.dgh = dgh;
-  if (mava_ppo_get_matmul_mode() == 1) return mava_gru_scan_bwd_h2_launch(tk, s);  // rec_gru_h2.hip
+  if (mava_ctx_matmul_mode(ctx) == 1) return mava_gru_scan_bwd_h2_launch(tk, s);  // rec_gru_h2.hip
   hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(Rm / 32), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;

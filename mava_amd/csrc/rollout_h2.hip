@@ -641,8 +641,11 @@ __global__ __launch_bounds__(512, 2) void rollout_h2_kernel(RolloutArgs a, Rollo
   }
 }
 
+int g_rollout_last_instance = 0;  // diagnostic: which template instance the last launch used (see the export below)
+
 template <int NO, int S1A, int S1C, bool SHARED>
 int launch_rollout(const RolloutArgs& a, hipStream_t s) {
+  g_rollout_last_instance = NO * 100000 + S1A * 1000 + S1C * 10 + (SHARED ? 1 : 0);
   const RolloutLds L = make_rollout_lds<NO, S1A, S1C, SHARED>();
   MAVA_ARG_CHECK(L.end <= 163840, 8, "mava_rollout_ff_f32: %d bytes of LDS exceed the 160 KiB of a CU", L.end);
   static bool attr_set = false;
@@ -665,6 +668,11 @@ extern "C" int mava_debug_get_rollout_stamps(unsigned long long* out16) {
   return -(int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rollout_stamps), 16 * sizeof(unsigned long long));
 }
 #endif
+
+// Diagnostic (not part of include/mava_hip.h, like mava_debug_h2_launches): NO * 100000 + S1A * 1000 + S1C * 10 + SHARED
+// of the rollout_h2_kernel<NO, S1A, S1C, SHARED> instance the last mava_rollout_ff_f32 call launched, so that a parity
+// test can assert WHICH instantiation it checked (tests/test_gpu_learner.py).
+extern "C" int mava_debug_rollout_last_instance(void) { return g_rollout_last_instance; }
 
 extern "C" int mava_rollout_ff_f32(const float* actor_params, int n_actions, const float* critic_params, int critic_shared,
                                    int E, int A, int O, int T, int time_limit, uint64_t policy_seed, uint64_t env_seed,

@@ -40,6 +40,9 @@ class ObsSpec(NamedTuple):
 class SyntheticRware:
     # all agents of an env receive the same global_state row (mava/wrappers/jumanji.py:53-59)
     global_state_shared = True
+    # mava_rollout_ff_f32 (csrc/rollout_h2.hip) carries THIS generator's env phase: the feed-forward learner routes an
+    # env to the one-launch rollout only when it declares so (any other MarlEnv steps through step_into per time step)
+    supports_fused_rollout = True
 
     def __init__(self, num_envs: int, num_agents: int, obs_dim: int = 66, num_actions: int = 5, time_limit: int = 500,
                  add_global_state: bool = False, add_agent_id: bool = True, seed: int = 42, env_offset: int = 0,

@@ -21,7 +21,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import check, launch, lib, ptr, stream_ptr
+from ._lib import check, ctx_ptr, launch, lib, ptr, stream_ptr
 from .networks import _orthogonal_
 
 ACT = {"relu": 1, "tanh": 2}
@@ -74,6 +74,8 @@ class _Layer:
 
 class GenericNet:
     """torso (MLP or CNN) + Dense heads, forward / backward on T32 matrices."""
+
+    ctx = None  # the owning learner's context handle (_lib.Ctx: arithmetic of the products); None = exact f32
 
     def __init__(self, torso, din: int, heads: List[Tuple[str, int, float]], obs_shape: Optional[Tuple[int, int, int]] = None,
                  raw_tail: int = 0):
@@ -181,8 +183,7 @@ class GenericNet:
             out[off : off + math.prod(shape)].view(shape).copy_(v)
 
     # ----------------------------------------------------------------------------------- products
-    @staticmethod
-    def _dense(x_ptr: int, x_ld: int, K: int, w: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, N: int, rows: int,
+    def _dense(self, x_ptr: int, x_ld: int, K: int, w: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, N: int, rows: int,
                accumulate: bool = False, what: str = "gen_dense") -> None:
         """y (T32 rows x N) (+)= x (T32, x_ld features per tile) @ w (K x N) [+ bias], column-blocked."""
         L, s = lib(), stream_ptr()
@@ -190,12 +191,11 @@ class GenericNet:
             nb = min(128, N - n0)
             for k0 in range(0, K, 384):
                 kb = min(384, K - k0)
-                launch(what, L.mava_rec_dense_f32, x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, int(accumulate or k0 > 0),
+                launch(what, L.mava_rec_dense_f32, ctx_ptr(self.ctx), x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, int(accumulate or k0 > 0),
                        w.data_ptr() + 4 * (k0 * N + n0), N, (bias.data_ptr() + 4 * n0) if (bias is not None and k0 == 0) else None, None,
                        y.data_ptr() + 4 * 32 * n0, N, kb, nb, rows, 0, s)
 
-    @staticmethod
-    def _xty(x_ptr: int, x_ld: int, K: int, y: torch.Tensor, N: int, rows: int, slabs: torch.Tensor, gw: torch.Tensor,
+    def _xty(self, x_ptr: int, x_ld: int, K: int, y: torch.Tensor, N: int, rows: int, slabs: torch.Tensor, gw: torch.Tensor,
              gb: Optional[torch.Tensor], scale: float, accumulate: bool, gb_accumulate: Optional[bool] = None) -> None:
         """gw (K x N) (+)= scale * x^T y ; gb (N) (+)= scale * colsum(y)"""
         from . import ops
@@ -206,7 +206,7 @@ class GenericNet:
             for k0 in range(0, K, 128):
                 kb = min(128, K - k0)
                 want_b = int(gb is not None and k0 == 0)
-                launch("gen_xty", L.mava_rec_xty_f32, x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, y.data_ptr() + 4 * 32 * n0, N, kb, nb,
+                launch("gen_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, y.data_ptr() + 4 * 32 * n0, N, kb, nb,
                        rows, want_b, scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
                 blk = torch.empty(kb * nb, device=y.device)
                 ops.slab_reduce(slabs, kb * nb, blk)
@@ -359,6 +359,14 @@ class _GenericFF:
     """Shared part of the general feed-forward actor / critic: Flax-shaped trees over GenericNet's flat layout."""
 
     net: GenericNet
+
+    @property
+    def ctx(self):
+        return self.net.ctx
+
+    @ctx.setter
+    def ctx(self, value) -> None:  # FFLearner hands its context handle to the networks it drives
+        self.net.ctx = value
 
     @property
     def num_params(self) -> int:

@@ -30,6 +30,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from . import ops, parallel
+from .guards import check_f16_range
 from .networks import FeedForwardActor, FeedForwardValueNet, MLPTorso, make_action_head
 from .types import (AdamState, ExperimentOutput, LearnerState, Observation, ObservationGlobalState, OptStates, Params,
                     TimeStep)
@@ -185,13 +186,21 @@ class FFLearner:
         self.matmul_mode = str(s.get("matmul_mode", None) or os.environ.get("MAVA_MATMUL", "f16x2"))
         if self.matmul_mode not in ("f16x2", "f32"):
             raise ValueError(f"system.matmul_mode must be 'f16x2' or 'f32', got {self.matmul_mode!r}")
-        ops.lib().mava_ppo_set_matmul_mode(1 if self.matmul_mode == "f16x2" else 0)
+        # the library keeps no process-wide settings: arithmetic mode, critic aggregation and the kernels' own workspaces
+        # belong to this learner's context handle (include/mava_hip.h mava_ctx_*)
+        self.ctx = ops.Ctx(self.matmul_mode, critic_aggregation=os.environ.get("MAVA_CRITIC_AGGREGATION", "1") != "0")
+        for net_ in (self.actor_network, self.critic_network):
+            net_.ctx = self.ctx
         # the whole rollout in one launch (rollout_h2.hip) when the shape is instantiated; MAVA_FUSED_ROLLOUT=0 keeps
         # the per-step kernels
+        # (mava_rollout_ff_f32 hard-codes the synthetic generator's env phase: only an env that declares the capability -
+        # SyntheticRware.supports_fused_rollout - is routed there; any other MarlEnv keeps the per-step kernels)
         self.fused_rollout = (self.matmul_mode == "f16x2" and not self.continuous and not self.generic
                               and os.environ.get("MAVA_FUSED_ROLLOUT", "1") != "0"
+                              and bool(getattr(env0, "supports_fused_rollout", False))
                               and int(getattr(env0, "synth_state_dim", 0)) == 0
                               and (not centralised_critic or (env0.gs_tiles == 1 and env0.global_state_shared)))
+        self._learn_calls = 0  # guards.check_f16_range: the previous call's metrics are checked from the second call on
 
     def _timed(self, name: str, fn, *args, **kwargs):
         """Run one kernel launch, optionally bracketed by HIP events on the launch stream."""
@@ -357,7 +366,7 @@ class FFLearner:
                 shared = self.critic_share == self.A and self.A > 1
                 common = dict(critic_share=1 if shared else self.critic_share, critic_rows=self.E if shared else EA,
                               value_broadcast=self.A if shared else 1, seed=self.seed, step=step,
-                              step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA)
+                              step_base=self.step_dev, row_offset=(self.rank * self.U + u) * EA, ctx=self.ctx)
                 if self.generic:
                     self._timed("policy_step", self._generic_act, u, rep, t, step)
                 elif self.continuous:
@@ -389,10 +398,10 @@ class FFLearner:
                                                     self.E, self.A)[0]
                 rep.last_val.view(EA).copy_(v)
             else:
-                ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share, out=rep.last_val.view(EA, 1))
+                ops.mlp_forward(pc, self.Oc, 1, cx, rows=EA, x_share=self.critic_share, out=rep.last_val.view(EA, 1), ctx=self.ctx)
             self._timed("gae", ops.gae, rep.reward.view(self.T, EA), rep.value.view(self.T, EA), rep.done.view(self.T, EA),
                         rep.last_val.view(EA), float(s.gamma), float(s.gae_lambda),
-                        out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)))
+                        out=(rep.adv.view(self.T, EA), rep.tgt.view(self.T, EA)), ctx=self.ctx)
 
     def _minibatch(self, n: int, k: int, mb: int, perm: Optional[torch.Tensor]) -> None:
         """ff_mappo.py:144-266 for minibatch `mb` of epoch `k`."""
@@ -429,7 +438,7 @@ class FFLearner:
             av = rep.agents_view[:T].view(TEA, self.Oa)
             cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
             self._timed("critic_grad", ops.ppo_critic_grad, pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA),
-                        idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c)
+                        idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c, ctx=self.ctx)
             ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=u > 0)
         w_rest = parallel.allreduce_sum_async(self.g[self.Pa :])  # critic gradient + the loss scalars
         for wk in (w_actor, w_rest):
@@ -573,6 +582,10 @@ class FFLearner:
         """LearnerFn (mava/types.py:154): num_updates_per_eval updates, asynchronous on the current
         stream - the caller synchronises before reading the clock (ff_mappo.py:497-498)."""
         self.adopt(learner_state)
+        if self.matmul_mode == "f16x2":
+            obs = [t for r in self.reps for t in (r.agents_view[0], r.global_state[0] if self.centralised else None)]
+            check_f16_range(self.p, obs, self.train_metrics if self._learn_calls else None, type(self).__name__)
+        self._learn_calls += 1
         for n in range(self.n_upd):
             self.update(n)
         U = self.U

@@ -10,7 +10,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import Ctx, check, ctx_ptr, lib, ptr, stream_ptr
 
 
 def _req(t: torch.Tensor, dtype: torch.dtype, name: str, shape: Optional[Tuple[int, ...]] = None) -> None:
@@ -41,7 +41,7 @@ def permutation(n: int, seed: int, counter: int, out: Optional[torch.Tensor] = N
     return out
 
 
-def gae(reward, value, done, last_val, gamma: float, gae_lambda: float, last_done=None, out=None):
+def gae(reward, value, done, last_val, gamma: float, gae_lambda: float, last_done=None, out=None, ctx: Optional[Ctx] = None):
     """(advantages, targets) for time-major (T, ...) inputs; see mava_gae_f32."""
     T = reward.shape[0]
     N = reward[0].numel() if T > 0 else last_val.numel()
@@ -65,7 +65,7 @@ def gae(reward, value, done, last_val, gamma: float, gae_lambda: float, last_don
         _req(adv, torch.float32, "adv", reward.shape)
         _req(tgt, torch.float32, "tgt", reward.shape)
     check(
-        lib().mava_gae_f32(ptr(reward), ptr(value), ptr(done), ptr(last_val), ptr(last_done), T, N,
+        lib().mava_gae_f32(ctx_ptr(ctx), ptr(reward), ptr(value), ptr(done), ptr(last_val), ptr(last_done), T, N,
                            gamma, gae_lambda, ptr(adv), ptr(tgt), stream_ptr()),
         "mava_gae_f32",
     )
@@ -122,7 +122,7 @@ def mlp_param_count(din: int, n_out: int) -> int:
 
 
 def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, rows: Optional[int] = None,
-                x_share: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                x_share: int = 1, out: Optional[torch.Tensor] = None, ctx: Optional[Ctx] = None) -> torch.Tensor:
     """Raw network outputs (rows, n_out); x is (rows_x, din) and output row r reads x[r // x_share]."""
     _req(params, torch.float32, "params")
     if params.numel() != mlp_param_count(din, n_out):
@@ -140,7 +140,7 @@ def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, row
         _req(out, torch.float32, "out")
         if out.numel() != rows * n_out:
             raise ValueError(f"out: expected {rows * n_out} elements, got {out.numel()}")
-    check(lib().mava_mlp_forward_f32(ptr(params), din, n_out, ptr(x), x_share, rows, ptr(out), stream_ptr()),
+    check(lib().mava_mlp_forward_f32(ctx_ptr(ctx), ptr(params), din, n_out, ptr(x), x_share, rows, ptr(out), stream_ptr()),
           "mava_mlp_forward_f32")
     return out
 
@@ -148,7 +148,7 @@ def mlp_forward(params: torch.Tensor, din: int, n_out: int, x: torch.Tensor, row
 def policy_step(actor_params, critic_params, agents_view, action_mask, critic_input, *, n_actions: int,
                 critic_share: int = 1, critic_rows: Optional[int] = None, value_broadcast: int = 1, seed: int,
                 step: int, row_offset: int = 0, greedy: bool = False, forced_action=None, out=None,
-                want_logits: bool = False, step_base: Optional[torch.Tensor] = None):
+                want_logits: bool = False, step_base: Optional[torch.Tensor] = None, ctx: Optional[Ctx] = None):
     """One acting step: returns (action i32 (rows), log_prob (rows), value, logits|None).  `step_base` (a device
     int32 word) is added to `step` on the device."""
     if step_base is not None:
@@ -186,7 +186,7 @@ def policy_step(actor_params, critic_params, agents_view, action_mask, critic_in
             raise ValueError("policy_step: output buffers have the wrong size")
     logits = torch.empty((rows, n_actions), dtype=torch.float32, device=dev) if want_logits else None
     check(
-        lib().mava_policy_step_f32(ptr(actor_params), actor_din, n_actions, ptr(agents_view), ptr(action_mask),
+        lib().mava_policy_step_f32(ctx_ptr(ctx), ptr(actor_params), actor_din, n_actions, ptr(agents_view), ptr(action_mask),
                                    ptr(critic_params), critic_din, ptr(critic_input), critic_share, critic_rows,
                                    value_broadcast, rows, seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFF,
                                    ptr(step_base), row_offset & 0xFFFFFFFF, int(greedy), ptr(forced_action), ptr(action),
@@ -204,7 +204,8 @@ def continuous_param_count(din: int, action_dim: int) -> int:
 def policy_step_continuous(actor_params, critic_params, agents_view, critic_input, *, action_dim: int,
                            critic_share: int = 1, critic_rows: Optional[int] = None, value_broadcast: int = 1,
                            seed: int, step: int, row_offset: int = 0, greedy: bool = False, forced_action=None,
-                           out=None, want_mean: bool = False, step_base: Optional[torch.Tensor] = None):
+                           out=None, want_mean: bool = False, step_base: Optional[torch.Tensor] = None,
+                           ctx: Optional[Ctx] = None):
     """One acting step with the continuous head: returns (action f32 (rows, action_dim), log_prob (rows), value,
     mean|None)."""
     if step_base is not None:
@@ -239,7 +240,7 @@ def policy_step_continuous(actor_params, critic_params, agents_view, critic_inpu
             raise ValueError("out: wrong sizes")
     mean = torch.empty((rows, action_dim), dtype=torch.float32, device=dev) if want_mean else None
     check(
-        lib().mava_policy_step_continuous_f32(ptr(actor_params), actor_din, action_dim, ptr(agents_view),
+        lib().mava_policy_step_continuous_f32(ctx_ptr(ctx), ptr(actor_params), actor_din, action_dim, ptr(agents_view),
                                               ptr(critic_params), critic_din, ptr(critic_input), critic_share,
                                               critic_rows, value_broadcast, rows, seed & 0xFFFFFFFFFFFFFFFF,
                                               step & 0xFFFFFFFF, ptr(step_base), row_offset & 0xFFFFFFFF, int(greedy),
@@ -332,8 +333,10 @@ def _check_idx(idx, idx_base, Rb, TE):
 
 
 def ppo_actor_grad(params, agents_view, action_mask, action, old_log_prob, advantages, stats, idx, idx_base: int,
-                   Rb: int, A: int, n_actions: int, clip_eps: float, ent_coef: float, slab: torch.Tensor) -> None:
-    """Fills slab (n_slab, stride) with partial [actor gradient | actor_loss, entropy] sums."""
+                   Rb: int, A: int, n_actions: int, clip_eps: float, ent_coef: float, slab: torch.Tensor,
+                   ctx: Optional[Ctx] = None) -> None:
+    """Fills slab (n_slab, stride) with partial [actor gradient | actor_loss, entropy] sums.  `ctx` selects the arithmetic
+    (None: exact f32)."""
     _req(agents_view, torch.float32, "agents_view")
     rows, din = agents_view.shape
     if rows % A:
@@ -360,7 +363,7 @@ def ppo_actor_grad(params, agents_view, action_mask, action, old_log_prob, advan
     if slab.dim() != 2 or slab.shape[1] < P + 2:
         raise ValueError("slab must be (n_slab, >= P+2)")
     check(
-        lib().mava_ppo_actor_grad_f32(ptr(params), din, n_actions, ptr(agents_view), ptr(action_mask), ptr(action),
+        lib().mava_ppo_actor_grad_f32(ctx_ptr(ctx), ptr(params), din, n_actions, ptr(agents_view), ptr(action_mask), ptr(action),
                                       ptr(old_log_prob), ptr(advantages), ptr(stats), ptr(idx), idx_base, Rb, A,
                                       clip_eps, ent_coef, ptr(slab), slab.shape[1], slab.shape[0], stream_ptr()),
         "mava_ppo_actor_grad_f32",
@@ -368,8 +371,9 @@ def ppo_actor_grad(params, agents_view, action_mask, action, old_log_prob, advan
 
 
 def ppo_critic_grad(params, critic_input, x_share: int, old_value, targets, idx, idx_base: int, Rb: int, A: int,
-                    clip_eps: float, vf_coef: float, slab: torch.Tensor) -> None:
-    """Fills slab (n_slab, stride) with partial [critic gradient | value_loss, 0] sums."""
+                    clip_eps: float, vf_coef: float, slab: torch.Tensor, ctx: Optional[Ctx] = None) -> None:
+    """Fills slab (n_slab, stride) with partial [critic gradient | value_loss, 0] sums.  `ctx` selects the arithmetic and
+    the aggregation of shared input rows (None: exact f32, aggregation on)."""
     _req(critic_input, torch.float32, "critic_input")
     din = critic_input.shape[1]
     _req(params, torch.float32, "params")
@@ -390,7 +394,7 @@ def ppo_critic_grad(params, critic_input, x_share: int, old_value, targets, idx,
     if slab.dim() != 2 or slab.shape[1] < P + 2:
         raise ValueError("slab must be (n_slab, >= P+2)")
     check(
-        lib().mava_ppo_critic_grad_f32(ptr(params), din, ptr(critic_input), x_share, ptr(old_value), ptr(targets),
+        lib().mava_ppo_critic_grad_f32(ctx_ptr(ctx), ptr(params), din, ptr(critic_input), x_share, ptr(old_value), ptr(targets),
                                        ptr(idx), idx_base, Rb, A, clip_eps, vf_coef, ptr(slab), slab.shape[1],
                                        slab.shape[0], stream_ptr()),
         "mava_ppo_critic_grad_f32",

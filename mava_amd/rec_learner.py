@@ -25,6 +25,7 @@ import torch
 
 from . import ops, parallel
 from ._lib import check, launch, lib, ptr, stream_ptr
+from .guards import check_f16_range
 from .learner import NUM_CU, _Replica
 from .networks import MLPTorso, make_action_head
 from .rec_networks import H, RecurrentActor, RecurrentValueNet, RecWorkspace, rows_to_t32, t32_to_rows
@@ -84,7 +85,7 @@ class RecLearner:
         self.matmul_mode = str(s.get("matmul_mode", None) or os.environ.get("MAVA_MATMUL", "f16x2"))
         if self.matmul_mode not in ("f16x2", "f32"):
             raise ValueError(f"system.matmul_mode must be 'f16x2' or 'f32', got {self.matmul_mode!r}")
-        lib().mava_ppo_set_matmul_mode(1 if self.matmul_mode == "f16x2" else 0)
+        self.ctx = ops.Ctx(self.matmul_mode)  # this learner's context handle (include/mava_hip.h mava_ctx_*): no process-wide mode
         if env.num_envs != self.E:
             raise ValueError(f"env.num_envs={env.num_envs} != arch.num_envs={self.E}")
         if centralised_critic and not getattr(env, "add_global_state", False):
@@ -141,13 +142,13 @@ class RecLearner:
                           and not c.get("use_layer_norm", False) for c in cfgs)
             return tuple((MLPTorso if default else GenericMLPTorso)(**c) for c in cfgs)
 
-        mk = lambda c: None
         hsd = int(net.get("hidden_state_dim", 128))
         env0 = self.reps[0].env
         obs_shape = getattr(env0, "obs_shape", None)  # (H, W, C) observations for CNN pre-torsos (env.synthetic.obs_shape)
         state_shape = getattr(env0, "state_shape", None) if centralised_critic else obs_shape
         self.actor_network = RecurrentActor(*torsos(net.actor_network), action_head, self.Oa, hsd, obs_shape)
         self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd, state_shape)
+        self.actor_network.ctx = self.critic_network.ctx = self.ctx
         self.generic_nets = self.actor_network.generic or self.critic_network.generic
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
         self.P = self.Pa + self.Pc
@@ -182,6 +183,7 @@ class RecLearner:
         self.dscale_partials = torch.zeros((self.ws.loss_partials.shape[0], max(self.nA, 1)), device=d)
         self.seed = int(s.seed)
         self._t_range = torch.arange(self.T, device=d, dtype=torch.int64)[:, None] * self.E
+        self._learn_calls = 0  # guards.check_f16_range
 
     # ------------------------------------------------------------------------------------ setup
     def init_params(self, actor_seed: int, critic_seed: int) -> None:
@@ -343,7 +345,8 @@ class RecLearner:
                                                      rep.dones.view(1, E, A), rep.h_critic, True, None, 1, EA, E, A, training=False,
                                                      y_out=rep.last_val)
             ops.gae(rep.reward.view(T, EA), rep.value.view(T, EA), rep.done_in.view(T, EA), rep.last_val.view(EA),
-                    float(s.gamma), float(s.gae_lambda), last_done=rep.dones.view(EA), out=(rep.adv.view(T, EA), rep.tgt.view(T, EA)))
+                    float(s.gamma), float(s.gae_lambda), last_done=rep.dones.view(EA), out=(rep.adv.view(T, EA), rep.tgt.view(T, EA)),
+                    ctx=self.ctx)
 
     def _minibatch(self, n: int, k: int, mb: int, perm: torch.Tensor) -> None:
         s = self.config.system
@@ -457,6 +460,10 @@ class RecLearner:
 
     def learn(self, learner_state: RNNLearnerState) -> ExperimentOutput:
         self.adopt(learner_state)
+        if self.matmul_mode == "f16x2":
+            obs = [t for r in self.reps for t in (r.agents_view[0], r.global_state[0] if self.centralised else None)]
+            check_f16_range(self.p, obs, self.train_metrics if self._learn_calls else None, type(self).__name__)
+        self._learn_calls += 1
         for n in range(self.n_upd):
             self.update(n)
         U = self.U

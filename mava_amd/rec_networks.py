@@ -20,7 +20,7 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import check, launch, lib, ptr, stream_ptr
+from ._lib import check, ctx_ptr, launch, lib, ptr, stream_ptr
 from .distributions import Categorical
 from .networks import ContinuousActionHead, DiscreteActionHead, MLPTorso, _orthogonal_
 
@@ -55,6 +55,18 @@ class RecWorkspace:
 
 class _RecurrentNet:
     head_scale = 1.0
+    _ctx = None  # the owning learner's context handle (_lib.Ctx: arithmetic of the products / scans); None = exact f32
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    @ctx.setter
+    def ctx(self, value) -> None:
+        self._ctx = value
+        if getattr(self, "generic", False):  # the general pre / post torsos run their products on the same handle
+            self.pre.ctx = value
+            self.post.ctx = value
 
     def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None, obs_shape=None):
         if hidden_state_dim != H:
@@ -253,8 +265,8 @@ class _RecurrentNet:
 
             wpre, wpost, _ = self._gen_ws(ws, training)
             feat = self.pre.forward(flat[: self.pre.num_params], wpre, x_ext, x_share, idx, Rm, E, A, T=T)[0]
-            GenericNet._dense(feat.data_ptr(), self.Np, self.Np, self.seg(flat, "Wi"), self.seg(flat, "bi"), ws.gi, G3, rows, what="rec_dense(gi)")
-            launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
+            self.pre._dense(feat.data_ptr(), self.Np, self.Np, self.seg(flat, "Wi"), self.seg(flat, "bi"), ws.gi, G3, rows, what="rec_dense(gi)")
+            launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
                    ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
             if stop_after_scan:
                 raise NotImplementedError("the fused output path serves the default torsos only")
@@ -266,7 +278,7 @@ class _RecurrentNet:
         # pre-torso: inputs wider than 384 are consumed in column blocks (accumulating products; the weight
         # slice of one block stays register-resident), the ReLU rides on the last block
         din, Wpre = self.din, self.seg(flat, "Wpre")
-        t32_in = training and ws.xin is not None and L.mava_ppo_get_matmul_mode() == 1
+        t32_in = training and ws.xin is not None and (self.ctx is not None and self.ctx.matmul_mode == "f16x2")
         kp = -(-din // 32) * 32
         if t32_in:
             launch("rec_gather", L.mava_rec_gather_t32_f32, ptr(x_ext), ptr(idx), Rm, E, A, x_share, din, din, rows, kp, ptr(ws.xin), s)
@@ -275,23 +287,23 @@ class _RecurrentNet:
             kc = min(384, din - k0)
             last = k0 + kc >= din
             if t32_in:  # column block k0 of a T32 tile starts k0 * 32 floats into the tile
-                launch("rec_dense(pre)", L.mava_rec_dense_f32, ws.xin.data_ptr() + 4 * 32 * k0, 0, None, 0, 0, 0, 1, kp, int(k0 > 0),
+                launch("rec_dense(pre)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ws.xin.data_ptr() + 4 * 32 * k0, 0, None, 0, 0, 0, 1, kp, int(k0 > 0),
                        Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), 0, kc, H, rows, int(last), s)
             else:
-                launch("rec_dense(pre)", L.mava_rec_dense_f32, x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din,
+                launch("rec_dense(pre)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), x_ext.data_ptr() + 4 * k0, 1, ptr(idx), Rm, E, A, x_share, din,
                        int(k0 > 0), Wpre.data_ptr() + 4 * k0 * H, H, W("bpre") if k0 == 0 else None, None, ptr(ws.xpre), 0, kc, H, rows,
                        int(last), s)
             k0 += kc
-        launch("rec_dense(gi)", L.mava_rec_dense_f32, ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), 0, H,
+        launch("rec_dense(gi)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ptr(ws.xpre), 0, None, 0, 0, 0, 1, H, 0, W("Wi"), G3, W("bi"), None, ptr(ws.gi), 0, H,
                G3, rows, 0, s)
-        launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
+        launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
                ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
         if stop_after_scan:  # the output path runs fused (fused_output)
             return ws.hs
-        launch("rec_dense(post)", L.mava_rec_dense_f32, ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None,
+        launch("rec_dense(post)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ptr(ws.hs), 0, None, 0, 0, 0, 1, H, 0, W("Wpost"), H, W("bpost"), None,
                ptr(ws.post), 0, H, H, rows, 1, s)
         y = ws.y if y_out is None else y_out
-        launch("rec_dense(head)", L.mava_rec_dense_f32, ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"),
+        launch("rec_dense(head)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ptr(ws.post), 0, None, 0, 0, 0, 1, H, 0, W("Whead"), self.n_out, W("bhead"),
                None, ptr(y), 0, H, self.n_out, rows, 0, s)
         return y
 
@@ -326,15 +338,15 @@ class _RecurrentNet:
             fpost = flat[self.post_off : self.post_off + self.post.num_params]
             gpost = grad_out[self.post_off : self.post_off + self.post.num_params]
             self.post.backward(fpost, wpost, [ws.dy], gpost, accumulate, grad_scale, dx_out=ws.dh_out)
-            launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
+            launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
                    ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
             o = lambda n: self.off[n][0]
             Np = self.Np
-            GenericNet._xty(wpre.feat_in.data_ptr(), Np, Np, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * G3],
+            self.pre._xty(wpre.feat_in.data_ptr(), Np, Np, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * G3],
                             grad_out[o("bi") : o("bi") + G3], 1.0 / grad_scale, accumulate)
             # dW_h, and db_hn = the n part of colsum(dgh) (taken from a scratch vector: r and z have no hidden-side bias)
             tmp_b = torch.empty(G3, device=flat.device)
-            GenericNet._xty(ws.hprev.data_ptr(), H, H, ws.dgh, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
+            self.pre._xty(ws.hprev.data_ptr(), H, H, ws.dgh, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
                             1.0 / grad_scale, accumulate, gb_accumulate=False)
             gbhn = grad_out[o("bhn") : o("bhn") + H]
             if accumulate:
@@ -342,7 +354,7 @@ class _RecurrentNet:
             else:
                 gbhn.copy_(tmp_b[2 * H :])
             WiT = self.seg(flat, "Wi").t().contiguous()
-            GenericNet._dense(ws.dgi.data_ptr(), G3, G3, WiT, None, dfeat, Np, rows, what="rec_dense(bwd)")
+            self.pre._dense(ws.dgi.data_ptr(), G3, G3, WiT, None, dfeat, Np, rows, what="rec_dense(bwd)")
             self.pre.backward(flat[: self.pre.num_params], wpre, [], grad_out[: self.pre.num_params], accumulate, grad_scale, d_feat=dfeat)
             return
         # transposed weights for the dX = dY W^T products (tiny, re-materialised per call)
@@ -350,18 +362,18 @@ class _RecurrentNet:
         WpostT = self.seg(flat, "Wpost").t().contiguous()
         WiT = self.seg(flat, "Wi").t().contiguous()
         d = lambda k, N, x, w, ldw, gate, y: launch(
-            "rec_dense(bwd)", L.mava_rec_dense_f32, ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), 0, k, N,
+            "rec_dense(bwd)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), 0, k, N,
             rows, 0, s)
         if not from_scan:  # (from_scan: fused_output already left ws.dh_out and the output path's gradients)
             d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
             d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
-        launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved),
+        launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved),
                ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
         d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
 
         def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
             """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
-            launch("rec_xty", L.mava_rec_xty_f32, x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0, K, N,
+            launch("rec_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0, K, N,
                    rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
             ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
             if b_off is not None:
@@ -374,7 +386,7 @@ class _RecurrentNet:
             xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
         xty(ptr(ws.xpre), 0, H, H, G3, ws.dgi, o("Wi"), o("bi"), G3)
         xty(ptr(ws.hprev), 0, H, H, G3, ws.dgh, o("Wh"), o("bhn"), H, bias_slice=2 * H)  # db_hn: n-part of colsum(dgh)
-        t32_in = ws.xin is not None and L.mava_ppo_get_matmul_mode() == 1  # the forward pass left the gathered input in ws.xin
+        t32_in = ws.xin is not None and (self.ctx is not None and self.ctx.matmul_mode == "f16x2")  # the forward pass left the gathered input in ws.xin
         kp = -(-self.din // 32) * 32
         k0 = 0
         while k0 < self.din:  # column blocks of wide inputs (each block's rows of W_pre are contiguous)

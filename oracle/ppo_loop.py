@@ -51,8 +51,11 @@ class OracleLearner:
             return np.repeat(obs["global_state"][:, :1, :], self.A, 1).astype(np.float64)
         return obs["agents_view"].astype(np.float64)
 
-    def _rollout(self, d, u):
-        """ff_mappo.py:76-106 for one (rank, replica)."""
+    def _rollout(self, d, u, forced_action=None):
+        """ff_mappo.py:76-106 for one (rank, replica).  `forced_action` (T, E, A) int: "identical trajectory inputs" in
+        the strict sense - the sampled action is an INPUT (the oracle still draws its own and records it as
+        tr["own_action"], with the Gumbel-score margin between the two in tr["action_margin"], so that a test can show
+        that every disagreement is a near-tie of the argmax and nothing else)."""
         E, A, T, nA = self.E, self.A, self.T, self.nA
         env, obs = self.envs[d][u], self.obs[d][u]
         if self.actor_spec is not None:
@@ -66,6 +69,7 @@ class OracleLearner:
             a_fwd = lambda x: [po.mlp_forward(pa, x)]
             c_fwd = lambda x: po.mlp_forward(pc, x)
         tr = {k: [] for k in ("av", "cx", "mask", "action", "value", "reward", "log_prob", "done", "ret", "len", "term")}
+        own_action, margin = [], []
         for t in range(T):
             step = self.t_global + t
             av = obs["agents_view"].astype(np.float64)
@@ -84,6 +88,14 @@ class OracleLearner:
                 z = po.masked_logits(y, mask.reshape(E * A, nA))
                 uni = philox.policy_uniforms(self.seed, step, E * A, nA, row_offset=(d * self.U + u) * E * A)
                 action = po.gumbel_argmax(z, uni).reshape(E, A)
+                if forced_action is not None:
+                    fa_ = np.asarray(forced_action[t]).reshape(-1).astype(np.int64)
+                    with np.errstate(divide="ignore"):
+                        score = z - np.log(-np.log(uni))
+                    rows_ = np.arange(E * A)
+                    own_action.append(action.copy())
+                    margin.append((score[rows_, action.reshape(-1)] - score[rows_, fa_]).reshape(E, A))
+                    action = fa_.reshape(E, A).astype(action.dtype)
                 lp = po.log_softmax(z)[np.arange(E * A), action.reshape(-1)]
             value = c_fwd(cx.reshape(E * A, -1))[:, 0]
             obs, reward, done, info = env.step(step + 1, action=None if self.continuous else action)
@@ -93,17 +105,20 @@ class OracleLearner:
                 tr[k].append(v)
         self.obs[d][u] = obs
         tr = {k: np.stack(v, 0) for k, v in tr.items()}
+        if own_action:
+            tr["own_action"], tr["action_margin"] = np.stack(own_action, 0), np.stack(margin, 0)
         last_val = c_fwd(self._critic_in(obs).reshape(E * A, -1))[:, 0].reshape(E, A)  # ff_mappo.py:110
         tr["adv"], tr["tgt"] = po.gae(tr["reward"], tr["value"], tr["done"], last_val, self.h["gamma"], self.h["lam"])
         tr["last_val"] = last_val
         return tr
 
-    def update(self, permutations: List[np.ndarray]) -> Dict[str, np.ndarray]:
+    def update(self, permutations: List[np.ndarray], forced_actions=None) -> Dict[str, np.ndarray]:
         """One `_update_step` on every (rank, replica); returns train metrics (K, M, 4) and keeps the
-        trajectories of the call in self.last_traj[d][u]."""
+        trajectories of the call in self.last_traj[d][u].  forced_actions[d][u]: see _rollout."""
         E, A, T, K, M, nA = self.E, self.A, self.T, self.K, self.M, self.nA
         h = self.h
-        trajs = [[self._rollout(d, u) for u in range(self.U)] for d in range(self.D)]
+        trajs = [[self._rollout(d, u, None if forced_actions is None else forced_actions[d][u]) for u in range(self.U)]
+                 for d in range(self.D)]
         self.t_global += T
         self.last_traj = trajs
         metrics = np.zeros((K, M, 4))

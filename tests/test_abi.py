@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 14
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in mava_hip.h but not exported by libmavahip.so"
-    assert lib.mava_abi_version() == 2
+    assert lib.mava_abi_version() == 3
 
 
 def test_python_binding_matches_header():
@@ -29,11 +29,11 @@ def test_python_binding_matches_header():
 def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.lib()
     # rejected on the host before any launch
-    rc = lib.mava_gae_f32(None, None, None, None, None, -1, 4, 0.99, 0.95, None, None, None)
+    rc = lib.mava_gae_f32(None, None, None, None, None, None, -1, 4, 0.99, 0.95, None, None, None)
     assert rc <= -1000
     assert b"negative shape" in lib.mava_last_error()
     assert lib.mava_mlp_param_count(70, 5) == 26245 and lib.mava_mlp_param_count(264, 1) == 50561
-    rc = lib.mava_mlp_forward_f32(None, 70, 99, None, 1, 8, None, None)
+    rc = lib.mava_mlp_forward_f32(None, None, 70, 99, None, 1, 8, None, None)
     assert rc <= -1000
 
 
@@ -67,3 +67,24 @@ def test_permutation_abi_argument_errors():
     assert lib.mava_permutation_i32(0, 1, 0, None, None) <= -1000 and b"n=0" in lib.mava_last_error()
     assert lib.mava_permutation_i32(1 << 31, 1, 0, None, None) <= -1000
     assert lib.mava_permutation_i32(8, 1, 0, None, None) <= -1000 and b"null pointer" in lib.mava_last_error()
+
+
+def test_context_handles_are_independent():
+    """mava_ctx_*: settings live in handles, not in the process - two handles (two learners) keep their own values, and a
+    NULL handle means the defaults."""
+    a, b = _lib.Ctx("f16x2"), _lib.Ctx("f32", critic_aggregation=False)
+    assert a.matmul_mode == "f16x2" and b.matmul_mode == "f32"
+    assert a.get(a.CRITIC_AGGREGATION) == 1 and b.get(b.CRITIC_AGGREGATION) == 0
+    b.set(b.GAE_VARIANT, 13)
+    assert a.get(a.GAE_VARIANT) == 0 and b.get(b.GAE_VARIANT) == 13 and a.h2_launches == 0
+    lib = _lib.lib()
+    assert lib.mava_ctx_set(a.handle, 99, 0) <= -1000 and b"unknown key" in lib.mava_last_error()
+    assert lib.mava_ctx_set(a.handle, a.MATMUL_MODE, 7) <= -1000
+    assert lib.mava_ctx_set(None, 0, 0) <= -1000 and lib.mava_ctx_destroy(None) == 0
+    a.close()
+    b.close()
+    assert a.handle is None
+    for name in dir(lib):  # no process-wide setters are left in the ABI
+        assert "set_variant" not in name and "set_matmul" not in name
+    for gone in ("mava_ppo_set_matmul_mode", "mava_gae_set_variant", "mava_policy_set_variant", "mava_ppo_set_critic_aggregation"):
+        assert not hasattr(lib, gone), gone

@@ -19,11 +19,17 @@ def _t(a, dev, dtype=None):
 
 @pytest.fixture(params=[0, 1], ids=["f32", "f16x2"])
 def mode(request):
-    from mava_amd._lib import lib
+    """The arithmetic of the products lives in a context handle (no process-wide setting): _net() hands it to the nets."""
+    from mava_amd._lib import Ctx
 
-    lib().mava_ppo_set_matmul_mode(request.param)
+    global _CTX
+    _CTX = Ctx("f16x2" if request.param == 1 else "f32")
     yield request.param
-    lib().mava_ppo_set_matmul_mode(0)
+    _CTX.close()
+    _CTX = None
+
+
+_CTX = None
 
 
 def _net(case, din, heads, raw_tail=0):
@@ -32,10 +38,13 @@ def _net(case, din, heads, raw_tail=0):
     if case["kind"] == "mlp":
         torso = GenericMLPTorso(case["sizes"], case["act"], case["ln"])
         spec = go.spec_mlp(din, case["sizes"], [h[1] for h in heads], case["act"], case["ln"], raw_tail)
-        return GenericNet(torso, din, heads, raw_tail=raw_tail), spec
-    torso = CNNTorso(case["channels"], case["kernels"], case["strides"], case["act"], case["ln"])
-    spec = go.spec_cnn(case["shape"], case["channels"], case["kernels"], case["strides"], [h[1] for h in heads], case["act"], case["ln"], raw_tail)
-    return GenericNet(torso, din, heads, obs_shape=case["shape"], raw_tail=raw_tail), spec
+        net = GenericNet(torso, din, heads, raw_tail=raw_tail)
+    else:
+        torso = CNNTorso(case["channels"], case["kernels"], case["strides"], case["act"], case["ln"])
+        spec = go.spec_cnn(case["shape"], case["channels"], case["kernels"], case["strides"], [h[1] for h in heads], case["act"], case["ln"], raw_tail)
+        net = GenericNet(torso, din, heads, obs_shape=case["shape"], raw_tail=raw_tail)
+    net.ctx = _CTX
+    return net, spec
 
 
 CASES = [

@@ -267,17 +267,13 @@ def test_policy_sampling_distribution(dev):
 @pytest.fixture(params=[0, 1], ids=["f32", "f16x2"])
 def matmul_mode(request):
     """0: exact-f32 MFMA kernels (ppo_train.hip); 1: split-f16 operands (ppo_train_h2.hip) for the shapes it
-    instantiates (others fall back to the exact kernel).  Yields (mode, launches-on-the-f16x2-kernel counter)."""
-    import ctypes
+    instantiates (others fall back to the exact kernel).  Yields (mode, launches-on-the-f16x2-kernel counter, the context
+    handle that carries the mode: the library has no process-wide setting)."""
+    from mava_amd._lib import Ctx
 
-    from mava_amd._lib import lib
-
-    L = lib()
-    L.mava_debug_h2_launches.restype = ctypes.c_long
-    L.mava_ppo_set_matmul_mode(request.param)
-    before = L.mava_debug_h2_launches()
-    yield request.param, (lambda: L.mava_debug_h2_launches() - before)
-    L.mava_ppo_set_matmul_mode(0)
+    ctx = Ctx("f16x2" if request.param == 1 else "f32")
+    yield request.param, (lambda: ctx.h2_launches), ctx
+    ctx.close()
 
 
 def _traj(rng, TE, A, O, nA, shared_gs=True):
@@ -322,7 +318,7 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmu
     slab = torch.zeros((n_slab, P + 2), device=dev)
     stats = ops.adv_stats(_t(adv, dev), _t(idx, dev) if use_idx else None, base, Rb, A)
     ops.ppo_actor_grad(_t(flat, dev), _t(av, dev), _t(mask, dev), _t(action, dev), _t(old_lp, dev), _t(adv, dev), stats,
-                       _t(idx, dev) if use_idx else None, base, Rb, A, nA, 0.2, 0.01, slab)
+                       _t(idx, dev) if use_idx else None, base, Rb, A, nA, 0.2, 0.01, slab, ctx=matmul_mode[2])
     out = torch.zeros(P + 2, device=dev)
     ops.slab_reduce(slab, P + 2, out)
     torch.cuda.synchronize()
@@ -357,7 +353,7 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
 
     if agg == 0 and not shared:
         pytest.skip("aggregation only applies to shared critic inputs")
-    lib().mava_ppo_set_critic_aggregation(agg)
+    matmul_mode[2].set(matmul_mode[2].CRITIC_AGGREGATION, agg)
 
     rng = np.random.default_rng(TE + O)
     av, gs, mask, action, old_lp, adv, old_v, tgt = _traj(rng, TE, A, O, 5, shared_gs=shared)
@@ -374,11 +370,8 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
 
     P = flat.size
     slab = torch.zeros((n_slab, P + 2), device=dev)
-    try:
-        ops.ppo_critic_grad(_t(flat, dev), _t(gs, dev), share, _t(old_v, dev), _t(tgt, dev), _t(idx, dev) if use_idx else None,
-                            0, Rb, A, 0.2, 0.5, slab)
-    finally:
-        lib().mava_ppo_set_critic_aggregation(1)
+    ops.ppo_critic_grad(_t(flat, dev), _t(gs, dev), share, _t(old_v, dev), _t(tgt, dev), _t(idx, dev) if use_idx else None,
+                        0, Rb, A, 0.2, 0.5, slab, ctx=matmul_mode[2])
     out = torch.zeros(P + 2, device=dev)
     ops.slab_reduce(slab, P + 2, out)
     torch.cuda.synchronize()
@@ -468,8 +461,8 @@ def test_train_kernels_full_launch_shape(dev, matmul_mode):
     slab_c = torch.zeros((n_slab, Pc + 2), device=dev)
     stats = ops.adv_stats(adv_d, idx_d, 0, Rb, A)
     ops.ppo_actor_grad(_t(fa, dev), _t(av, dev), _t(mask, dev), _t(action, dev), _t(old_lp, dev), adv_d, stats, idx_d, 0,
-                       Rb, A, nA, 0.2, 0.01, slab_a)
-    ops.ppo_critic_grad(_t(fc, dev), _t(gs, dev), A, _t(old_v, dev), _t(tgt, dev), idx_d, 0, Rb, A, 0.2, 0.5, slab_c)
+                       Rb, A, nA, 0.2, 0.01, slab_a, ctx=matmul_mode[2])
+    ops.ppo_critic_grad(_t(fc, dev), _t(gs, dev), A, _t(old_v, dev), _t(tgt, dev), idx_d, 0, Rb, A, 0.2, 0.5, slab_c, ctx=matmul_mode[2])
     out_a = torch.zeros(Pa + 2, device=dev)
     out_c = torch.zeros(Pc + 2, device=dev)
     ops.slab_reduce(slab_a, Pa + 2, out_a)
@@ -505,7 +498,7 @@ def test_train_kernels_full_launch_shape(dev, matmul_mode):
 def test_gae_variants(dev, variant, T, N, rec):
     """Every chunk/lane mapping of the GAE kernel gives the same scan (incl. ragged T and multi-slab T)."""
     from mava_amd import ops
-    from mava_amd._lib import lib
+    from mava_amd._lib import Ctx
 
     rng = np.random.default_rng(variant * 7 + T)
     r = rng.standard_normal((T, N)).astype(np.float32)
@@ -514,13 +507,11 @@ def test_gae_variants(dev, variant, T, N, rec):
     lv = rng.standard_normal(N).astype(np.float32)
     ld = (rng.random(N) < 0.1) if rec else None
     want, want_t = po.gae(r, v, d, lv, 0.99, 0.95, last_done=ld)
-    lib().mava_gae_set_variant(variant)
-    try:
-        adv, tgt = ops.gae(_t(r, dev), _t(v, dev), _t(d, dev), _t(lv, dev), 0.99, 0.95,
-                           last_done=None if ld is None else _t(ld, dev))
-        torch.cuda.synchronize()
-    finally:
-        lib().mava_gae_set_variant(0)
+    ctx = Ctx()
+    ctx.set(ctx.GAE_VARIANT, variant)
+    adv, tgt = ops.gae(_t(r, dev), _t(v, dev), _t(d, dev), _t(lv, dev), 0.99, 0.95,
+                       last_done=None if ld is None else _t(ld, dev), ctx=ctx)
+    torch.cuda.synchronize()
     assert_close(adv.cpu().numpy(), want, 1e-5, f"adv variant {variant}")
     assert_close(tgt.cpu().numpy(), want_t, 1e-5, f"tgt variant {variant}")
 
@@ -532,7 +523,7 @@ def test_policy_kernels_both_variants(dev, variant):
     values, log-probs and sampled actions - with one critic pass per agent row and with one pass per env broadcast
     to the agents."""
     from mava_amd import ops
-    from mava_amd._lib import lib
+    from mava_amd._lib import Ctx
 
     rng = np.random.default_rng(77)
     E, A, O, nA = 257, 4, 66, 5  # ragged last tile
@@ -543,19 +534,17 @@ def test_policy_kernels_both_variants(dev, variant):
     gs = rng.standard_normal((E, A * O)).astype(np.float32)
     mask = rng.random((rows, nA)) > 0.2
     mask[:, 0] = True
-    lib().mava_policy_set_variant(variant)
-    try:
-        action, logp, value, logits = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
-                                                      n_actions=nA, critic_share=A, seed=99, step=5, row_offset=7,
-                                                      want_logits=True)
-        raw = ops.mlp_forward(_t(fc, dev), A * O, 1, _t(gs, dev), rows=rows, x_share=A)
-        # one critic pass per env, value written to all A agent slots
-        action_b, logp_b, value_b, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
-                                                       n_actions=nA, critic_share=1, critic_rows=E, value_broadcast=A,
-                                                       seed=99, step=5, row_offset=7)
-        torch.cuda.synchronize()
-    finally:
-        lib().mava_policy_set_variant(0)
+    ctx = Ctx()
+    ctx.set(ctx.POLICY_VARIANT, variant)
+    action, logp, value, logits = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                                  n_actions=nA, critic_share=A, seed=99, step=5, row_offset=7,
+                                                  want_logits=True, ctx=ctx)
+    raw = ops.mlp_forward(_t(fc, dev), A * O, 1, _t(gs, dev), rows=rows, x_share=A, ctx=ctx)
+    # one critic pass per env, value written to all A agent slots
+    action_b, logp_b, value_b, _ = ops.policy_step(_t(fa, dev), _t(fc, dev), _t(av, dev), _t(mask, dev), _t(gs, dev),
+                                                   n_actions=nA, critic_share=1, critic_rows=E, value_broadcast=A,
+                                                   seed=99, step=5, row_offset=7, ctx=ctx)
+    torch.cuda.synchronize()
     y = po.mlp_forward(po.mlp_unflatten(fa.astype(np.float64), O + A, nA), av.astype(np.float64))
     v = po.mlp_forward(po.mlp_unflatten(fc.astype(np.float64), A * O, 1), gs.astype(np.float64))[:, 0]
     assert_close(logits.cpu().numpy(), y, 1e-5, "logits")

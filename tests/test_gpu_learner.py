@@ -191,6 +191,132 @@ def test_learner_update_matches_oracle(dev, system, U, rollout, matmul, monkeypa
         assert L.fused_rollout and not L._graphs, "the fused rollout kernel did not run"
 
 
+def _check_traj(L, ora, n, ftol, max_flips=4):
+    """Trajectory of update n on every replica against the oracle's (which took the learner's sampled actions as
+    inputs): integer / byte leaves bit-exact, floats at ftol; every action the oracle itself would have sampled
+    differently must be a near-tie of the Gumbel-max (score margin < 1e-3)."""
+    flips = 0
+    for u in range(L.U):
+        rep, tr = L.reps[u], ora.last_traj[0][u]
+        own, margin = tr["own_action"], tr["action_margin"]
+        diff = own != tr["action"]
+        flips += int(diff.sum())
+        assert (margin[diff] < 1e-3).all(), f"sampled actions differ beyond a near-tie: margins {margin[diff]}"
+        assert np.array_equal(rep.done.cpu().numpy().astype(bool), tr["done"])
+        assert np.array_equal(rep.reward.cpu().numpy(), tr["reward"].astype(np.float32))
+        assert np.array_equal(rep.agents_view[: L.T].cpu().numpy(), tr["av"].astype(np.float32)), "recorded observations"
+        if L.centralised:
+            assert np.array_equal(rep.global_state[: L.T, :, 0].cpu().numpy(), tr["cx"][:, :, 0].astype(np.float32)), "recorded state"
+        assert np.array_equal(rep.action_mask[: L.T].cpu().numpy().astype(bool), tr["mask"].astype(bool))
+        assert np.array_equal(rep.info_terminal[n].cpu().numpy().astype(bool), tr["term"])
+        assert np.array_equal(rep.info_length[n].cpu().numpy(), tr["len"])
+        assert np.array_equal(rep.info_return[n].cpu().numpy(), tr["ret"].astype(np.float32))
+        assert_close(rep.value.cpu().numpy(), tr["value"], ftol, "values")
+        assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], ftol, "log_probs")
+        assert_close(rep.last_val.cpu().numpy(), tr["last_val"], ftol, "bootstrap value")
+        assert_close(rep.adv.cpu().numpy(), tr["adv"], ftol, "advantages")
+        assert_close(rep.tgt.cpu().numpy(), tr["tgt"], ftol, "targets")
+        a64, t64 = po.gae(rep.reward.cpu().numpy(), rep.value.cpu().numpy(), rep.done.cpu().numpy().astype(bool),
+                          rep.last_val.cpu().numpy(), 0.99, 0.95)
+        assert_close(rep.adv.cpu().numpy(), a64, 1e-5, "advantages on identical inputs")  # north_star
+        assert_close(rep.tgt.cpu().numpy(), t64, 1e-5, "targets on identical inputs")
+    assert flips <= max_flips, f"{flips} sampled actions differ from the oracle's own draw"
+    return flips
+
+
+# The rollout_h2_kernel instantiations the benchmarked configurations dispatch to (csrc/rollout_h2.hip, end of file):
+# instance id = NO * 100000 + S1A * 1000 + S1C * 10 + SHARED.
+@pytest.mark.parametrize("system,A,E,U,K,inst", [
+    ("ff_mappo", 4, 40, 1, 1, 805171),   # <8,5,17,true>: BASELINE config 2 / 3 (tiny- / small-4ag); 16 envs per block: 3 blocks, last ragged
+    ("ff_mappo", 2, 40, 1, 1, 805091),   # <8,5,9,true>: tiny-2ag with the centralised critic; 32 envs per block: 2 blocks, last ragged
+    ("ff_ippo", 2, 16, 2, 4, 805050),    # <8,5,5,false>: BASELINE config 1 at its OWN shape (16 envs, T = 128, U = 2, K = 4, M = 2)
+    ("ff_ippo", 4, 40, 1, 1, 805050),    # <8,5,5,false> with 4 agents, 3 blocks
+])
+def test_fused_rollout_instantiations_match_oracle(dev, system, A, E, U, K, inst, monkeypatch):
+    """ff_mappo.py:76-139 on the one-launch rollout at the BENCHMARKED template instances: O = 66, 5 actions, T = 128,
+    several workgroups with a ragged last one, a time limit of 20 (every env resets ~6 times per rollout), two whole
+    updates (the second starts from slot T of the first and from updated parameters) through learn()'s update(), own epoch
+    permutations, against OracleLearner on identical inputs.  The launch is asserted to be the intended instantiation."""
+    from mava_amd import envs
+    from mava_amd._lib import lib
+    from mava_amd.systems.ppo import ff_ippo, ff_mappo
+    from tests.conftest import check_and_sync_f16x2_state
+
+    monkeypatch.setenv("MAVA_FUSED_ROLLOUT", "1")
+    monkeypatch.setenv("MAVA_MATMUL", "f16x2")
+    O, nA, T, M, TL = 66, 5, 128, 2, 20
+    cfg = _cfg(system, A, E, T, K, M, U)
+    cfg.env.kwargs.time_limit = TL
+    cfg.system.num_updates_per_eval = 2
+    central = system == "ff_mappo"
+    mod = ff_mappo if central else ff_ippo
+    env, _ = envs.make(cfg, add_global_state=central, device=dev)
+    learn, _, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    rng = np.random.default_rng(A * 100 + E)
+    fa = po.mlp_flatten(po.init_mlp(rng, A + O, nA, 1.0)).astype(np.float32)
+    fc = po.mlp_flatten(po.init_mlp(rng, (A * O) if central else (A + O), 1, 1.0)).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=U, D=1, centralised=central, seed=42, time_limit=TL)
+    ora.set_params(fa, fc)
+    fn = lib().mava_debug_rollout_last_instance
+    n_term = 0
+    for n in range(2):
+        L.update(n)
+        torch.cuda.synchronize()
+        assert L.fused_rollout and fn() == inst, f"rollout instance {fn()} ran, wanted {inst}"
+        perms = [b.cpu().numpy() for b in L._perm_bufs]
+        res = ora.update(perms, forced_actions=[[r.action.cpu().numpy() for r in L.reps]])
+        _check_traj(L, ora, n, 5e-5)
+        n_term += int(sum(r.info_terminal[n].sum().item() for r in L.reps))
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        check_and_sync_f16x2_state(L, ora)
+    assert n_term >= 2 * U * E * (T // TL - 1), "the time limit must force resets inside the rollout"
+
+
+def test_fused_rollout_full_size_against_per_step_kernels(dev, monkeypatch):
+    """BASELINE config 2 at full size (4096 envs x 4 agents x 128 steps, 256 workgroups): the one-launch rollout against the
+    per-step kernels (mava_policy_step_f32 in exact f32 + mava_synth_rware_step + mava_gae_f32) from the same state.  The
+    environment outputs are bit-identical; sampled actions may differ only on near-ties of the Gumbel-max (two arithmetics);
+    values / log-probs / advantages / targets within 5e-5 of their rms."""
+    from mava_amd import envs
+    from mava_amd.systems.ppo import ff_mappo
+
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MAVA_FUSED_ROLLOUT", fused)
+        monkeypatch.setenv("MAVA_MATMUL", "f16x2")
+        cfg = _cfg("ff_mappo", 4, 4096, 128, 1, 2, 1)
+        cfg.env.kwargs.time_limit = 50
+        env, _ = envs.make(cfg, add_global_state=True, device=dev)
+        learn, _, state = ff_mappo.learner_setup(env, (42, 7, 8), cfg, device=dev)
+        L = learn.learner
+        rng = np.random.default_rng(5)
+        L.p[: L.Pa].copy_(torch.from_numpy(po.mlp_flatten(po.init_mlp(rng, 70, 5, 1.0)).astype(np.float32)))
+        L.p[L.Pa :].copy_(torch.from_numpy(po.mlp_flatten(po.init_mlp(rng, 264, 1, 1.0)).astype(np.float32)))
+        L._rollout(0)
+        torch.cuda.synchronize()
+        assert L.fused_rollout == (fused == "1")
+        r = L.reps[0]
+        outs.append({k: getattr(r, k).cpu().numpy() for k in ("agents_view", "global_state", "action_mask", "step_count", "action",
+                                                              "value", "reward", "log_prob", "done", "last_val", "adv", "tgt")}
+                    | {"ret": r.info_return[0].cpu().numpy(), "len": r.info_length[0].cpu().numpy(),
+                       "term": r.info_terminal[0].cpu().numpy()})
+        del learn, L, env
+        torch.cuda.empty_cache()
+    f, s = outs
+    for k in ("agents_view", "global_state", "action_mask", "step_count", "reward", "done", "ret", "len", "term"):
+        assert np.array_equal(f[k], s[k]), k
+    same = f["action"] == s["action"]
+    assert (~same).mean() < 2e-5, f"{int((~same).sum())} of {same.size} sampled actions differ"
+    assert_close(f["value"], s["value"], 5e-5, "values")
+    assert_close(f["last_val"], s["last_val"], 5e-5, "bootstrap values")
+    assert_close(np.where(same, f["log_prob"], 0.0), np.where(same, s["log_prob"], 0.0), 5e-5, "log-probs")
+    assert_close(f["adv"], s["adv"], 5e-5, "advantages")
+    assert_close(f["tgt"], s["tgt"], 5e-5, "targets")
+
+
 def test_graph_rollout_is_bit_identical(dev, monkeypatch):
     """The captured rollout (device-side step counter) against the eager launches, 5 updates."""
     from mava_amd import envs
@@ -312,3 +438,69 @@ def test_run_experiment_with_eval_and_checkpoint(dev, system, tmp_path, monkeypa
     assert run["step_0"]["step_count"] > 0 and len(run["step_0"]["mean_episode_return"]) == 1
     assert "steps_per_second" not in run["step_0"] or run["step_0"]["steps_per_second"][0] > 0
     assert len(run["absolute_metrics"]["mean_episode_return"]) == 1
+
+
+def _small_learner(dev, matmul, seed_keys=(42, 7, 8), E=16, T=8):
+    from mava_amd import envs
+    from mava_amd.systems.ppo import ff_mappo
+
+    cfg = _cfg("ff_mappo", 4, E, T, 2, 2, 1)
+    cfg.system.matmul_mode = matmul
+    cfg.system.num_updates_per_eval = 1
+    cfg.env.kwargs.time_limit = 5
+    env, _ = envs.make(cfg, add_global_state=True, device=dev)
+    learn, _, state = ff_mappo.learner_setup(env, seed_keys, cfg, device=dev)
+    return learn, state
+
+
+def test_f16_range_guard(dev):
+    """An operand beyond f16's range must not come back as finite-looking garbage (mava_amd/guards.py): the f16x2 learner
+    refuses observations / parameters >= 6e4 and reports a previous call's non-finite losses; the exact-f32 learner takes
+    the same inputs."""
+    from mava_amd._lib import MavaHipError
+
+    learn, state = _small_learner(dev, "f16x2")
+    L = learn.learner
+    out = learn(state)  # in range: fine
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()
+    L.reps[0].agents_view[0, 3, 1, 7] = 1.0e5
+    with pytest.raises(MavaHipError, match="observation"):
+        learn(out.learner_state)
+    L.reps[0].agents_view[0, 3, 1, 7] = 1.0
+    L.p[11] = -7.0e4
+    with pytest.raises(MavaHipError, match="parameters"):
+        learn(L.learner_state())
+    L.p[11] = 0.01
+    L.train_metrics[0, 0, 0, 0] = float("nan")  # what an overflowed activation leaves behind
+    with pytest.raises(MavaHipError, match="non-finite"):
+        learn(L.learner_state())
+    L.train_metrics.zero_()
+    learn(L.learner_state())
+    # exact f32: the same observation is legal and the update stays finite
+    learn32, state32 = _small_learner(dev, "f32")
+    learn32.learner.reps[0].agents_view[0, 3, 1, 7] = 1.0e5
+    out32 = learn32(state32)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out32.train_metrics["total_loss"]).all() and torch.isfinite(learn32.learner.p).all()
+
+
+def test_two_learners_with_different_arithmetic_share_nothing(dev):
+    """The library keeps no process-wide mode (include/mava_hip.h, mava_ctx_*): an f16x2 learner and an exact-f32 learner
+    interleaved in one process give bit for bit what each gives alone, and each handle counts its own f16x2 launches."""
+    solo = {}
+    for mm in ("f16x2", "f32"):
+        learn, state = _small_learner(dev, mm)
+        for _ in range(3):
+            state = learn(state).learner_state
+        torch.cuda.synchronize()
+        solo[mm] = learn.learner.p.clone()
+    la, sa = _small_learner(dev, "f16x2")
+    lb, sb = _small_learner(dev, "f32")
+    for _ in range(3):
+        sa = la(sa).learner_state
+        sb = lb(sb).learner_state
+    torch.cuda.synchronize()
+    assert torch.equal(la.learner.p, solo["f16x2"]) and torch.equal(lb.learner.p, solo["f32"])
+    assert not torch.equal(solo["f16x2"], solo["f32"])
+    assert la.learner.ctx.h2_launches == 3 * 2 * 2 * 2 and lb.learner.ctx.h2_launches == 0

@@ -30,11 +30,21 @@ def _from_t32(flat, rows, N):
 def rec_mode(request):
     """Arithmetic of the dense / X^T Y products on T32 operands: 0 exact-f32 MFMAs, 1 split-f16 operands
     (rec_dense_h2.hip; three f16 MFMAs per product, f32 accumulation)."""
-    from mava_amd._lib import lib
+    from mava_amd._lib import Ctx
 
-    lib().mava_ppo_set_matmul_mode(request.param)
+    global _CTX
+    _CTX = Ctx("f16x2" if request.param == 1 else "f32")  # the mode lives in a context handle: no process-wide setting
     yield request.param
-    lib().mava_ppo_set_matmul_mode(0)
+    _CTX.close()
+    _CTX = None
+
+
+_CTX = None
+
+
+def _cp():
+    """Context-handle argument of the direct C-ABI calls below (None = the library defaults: exact f32)."""
+    return None if _CTX is None else _CTX.handle
 
 
 @pytest.mark.parametrize("K,N,relu,gated", [(128, 384, False, False), (128, 128, True, False), (128, 13, False, False),
@@ -50,7 +60,7 @@ def test_rec_dense_t32(dev, K, N, relu, gated, rec_mode):
     g = rng.standard_normal((rows, N)).astype(np.float32)
     y = torch.zeros(rows * N, device=dev)
     xt, wt, bt, gt = _t(_to_t32(x), dev), _t(w, dev), _t(b, dev), _t(_to_t32(g), dev)
-    check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), 0, K, N,
+    check(lib().mava_rec_dense_f32(_cp(), ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, ptr(bt), ptr(gt) if gated else None, ptr(y), 0, K, N,
                                    rows, int(relu), stream_ptr()), "dense")
     torch.cuda.synchronize()
     want = x.astype(np.float64) @ w.astype(np.float64) + b
@@ -61,8 +71,7 @@ def test_rec_dense_t32(dev, K, N, relu, gated, rec_mode):
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want, 1e-5, "dense")
 
 
-@pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
-def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
+def test_rec_dense_rowmajor_gather_and_xty(dev, rec_mode):
     from mava_amd._lib import check, lib, ptr, stream_ptr
     from mava_amd import ops
 
@@ -78,7 +87,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     # NB: every device tensor handed to the C ABI is kept alive in a named variable (a temporary would be
     # freed - and its block recycled by the caching allocator - before the asynchronous kernel reads it)
     obs_d, idx_d, w_d, b_d = _t(obs, dev), _t(idx, dev), _t(w, dev), _t(b, dev)
-    check(lib().mava_rec_dense_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, 0, ptr(w_d), N, ptr(b_d), None,
+    check(lib().mava_rec_dense_f32(_cp(), ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, 0, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), 0, K, N, rows, 1, stream_ptr()), "dense gather")
     xg = obs[:, idx].reshape(rows, K).astype(np.float64)  # time-major, env-major inside a step
     want = np.maximum(xg @ w.astype(np.float64) + b, 0)
@@ -87,7 +96,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     # shared input rows (global state stored once per env)
     gs = rng.standard_normal((T, E, K)).astype(np.float32)
     gs_d = _t(gs, dev)
-    check(lib().mava_rec_dense_f32(ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, K, 0, ptr(w_d), N, ptr(b_d), None,
+    check(lib().mava_rec_dense_f32(_cp(), ptr(gs_d), 1, ptr(idx_d), Rm, E, A, A, K, 0, ptr(w_d), N, ptr(b_d), None,
                                    ptr(y), 0, K, N, rows, 0, stream_ptr()), "dense gather shared")
     want2 = np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64) @ w.astype(np.float64) + b
     assert_close(_from_t32(y.cpu().numpy(), rows, N), want2, 1e-5, "dense gather shared")
@@ -95,7 +104,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     dy = rng.standard_normal((rows, N)).astype(np.float32)
     dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), 0, K, N, rows, 1, 1.0,
+    check(lib().mava_rec_xty_f32(_cp(), ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), 0, K, N, rows, 1, 1.0,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -106,7 +115,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
     x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 0, 128, 384, rows, 1, 0.25,
+    check(lib().mava_rec_xty_f32(_cp(), ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 0, 128, 384, rows, 1, 0.25,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
@@ -122,12 +131,12 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, xty_variant, rec_mode):
         got_x = _from_t32(xin.cpu().numpy(), rows, kp)
         assert np.array_equal(got_x[:, :K], xs.astype(np.float32)) and not got_x[:, K:].any(), "gathered T32 input"
         if rec_mode == 1:  # (the exact-f32 kernel reads padded T32 inputs only when K is a multiple of 16)
-            check(lib().mava_rec_dense_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, 0, ptr(w_d), N, ptr(b_d), None, ptr(y), 0, K, N, rows, 1,
+            check(lib().mava_rec_dense_f32(_cp(), ptr(xin), 0, None, 0, 0, 0, 1, kp, 0, ptr(w_d), N, ptr(b_d), None, ptr(y), 0, K, N, rows, 1,
                                            stream_ptr()), "dense on the gathered input")
             assert_close(_from_t32(y.cpu().numpy(), rows, N), np.maximum(xs @ w.astype(np.float64) + b, 0), 1e-5,
                          "dense, gathered T32")
         slab = torch.zeros((5, K * N + N), device=dev)
-        check(lib().mava_rec_xty_f32(ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
+        check(lib().mava_rec_xty_f32(_cp(), ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
                                      stream_ptr()), "xty on the gathered input")
         out = torch.zeros(K * N + N, device=dev)
         ops.slab_reduce(slab, K * N + N, out)
@@ -162,6 +171,7 @@ def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA, rec
     rng = np.random.default_rng(11)
     obs, done, h0, idx = _seq_case(rng, T, E, A, Em, din, nA, shared)
     net = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
+    net.ctx = _CTX
     flat = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
     flat[net.off["bi"][0] : net.off["bi"][0] + 384] = rng.standard_normal(384) * 0.1
     flat[net.off["bhn"][0] : net.off["bhn"][0] + 128] = rng.standard_normal(128) * 0.1
@@ -180,26 +190,13 @@ def test_recurrent_forward_matches_oracle(dev, shared, T, E, A, Em, din, nA, rec
     assert_close(hs[:-1], hs_in[1:], 1e-5, "hidden states of every step")
 
 
-@pytest.fixture
-def xty_variant(request):
-    """0: exact-f32 MFMAs (default); 1: the six-bf16-product form of mava_rec_xty_f32."""
-    from mava_amd._lib import lib
-
-    lib().mava_rec_xty_set_variant(request.param)
-    yield request.param
-    lib().mava_rec_xty_set_variant(0)
-
-
-@pytest.mark.parametrize("xty_variant", [0, 1], indirect=True)
 # (128, 8, 8, 4, 155, 13): BPTT over the FULL sequence length of BASELINE config 4 (seq_len = 128, 8 agents, input 155,
 # 13 actions) - actor and critic gradients at the north-star 1e-4 against float64 autograd
 @pytest.mark.parametrize("T,E,A,Em,din,nA", [(6, 8, 4, 8, 20, 5), (12, 16, 8, 4, 40, 13), (128, 8, 8, 4, 155, 13)])
 @pytest.mark.parametrize("fused_out", [False, True], ids=["layerwise-out", "fused-out"])
-def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_variant, rec_mode, fused_out):
+def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, rec_mode, fused_out):
     """fused_out: post_torso -> head -> loss -> backward in one launch (mava_rec_out_f32) instead of eight."""
-    if xty_variant == 1 and rec_mode == 1:
-        pytest.skip("the bf16x6 X^T Y variant is an alternative to the f16x2 arithmetic, not a combination")
-    if fused_out and (rec_mode == 0 or xty_variant == 1):
+    if fused_out and rec_mode == 0:
         pytest.skip("the fused output path belongs to the f16x2 arithmetic")
     from mava_amd import ops
     from mava_amd._lib import check, lib, ptr, stream_ptr
@@ -211,6 +208,7 @@ def test_recurrent_gradients_match_autograd(dev, T, E, A, Em, din, nA, xty_varia
     Rm, rows = Em * A, T * Em * A
     actor = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
     critic = RecurrentValueNet(MLPTorso([128]), MLPTorso([128]), False, din)
+    actor.ctx = critic.ctx = _CTX
     fa = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
     fc = ro.init_rec(rng, din, 1, 1.0).astype(np.float32)
     mask = rng.random((T, E, A, nA)) > 0.25
@@ -363,7 +361,7 @@ def test_rec_dense_any_t32_width(dev, rec_mode):
         w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
         xt, wt = _t(_to_t32(x), dev), _t(w, dev)
         y = torch.zeros(rows * N, device=dev)
-        check(lib().mava_rec_dense_f32(ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, None, None, ptr(y), 0, K, N, rows, 0,
+        check(lib().mava_rec_dense_f32(_cp(), ptr(xt), 0, None, 0, 0, 0, 1, K, 0, ptr(wt), N, None, None, ptr(y), 0, K, N, rows, 0,
                                        stream_ptr()), "dense")
         torch.cuda.synchronize()
         assert_close(_from_t32(y.cpu().numpy(), rows, N), x.astype(np.float64) @ w.astype(np.float64), 1e-5, f"dense K={K} N={N}")
@@ -383,6 +381,7 @@ def test_recurrent_apply_and_eval_act_fn(dev):
     rng = np.random.default_rng(5)
     E, A, din, nA, steps = 5, 4, 23, 7, 4
     actor = RecurrentActor(MLPTorso([128]), MLPTorso([128]), DiscreteActionHead(nA), din)
+    actor.ctx = _CTX
     flat = ro.init_rec(rng, din, nA, 1.0).astype(np.float32)
     tree = actor.tree(_t(flat, dev), (1, 1))  # Flax-shaped, with (device, update_batch) leading dims
     assert torch.equal(actor.flat_from_tree(tree).cpu(), torch.from_numpy(flat))
@@ -409,6 +408,7 @@ def test_recurrent_apply_and_eval_act_fn(dev):
     # critic: centralised input, value shape (T, E, A), error without a global state
     S = 31
     critic = RecurrentValueNet(MLPTorso([128]), MLPTorso([128]), True, S)
+    critic.ctx = _CTX
     fc = ro.init_rec(rng, S, 1, 1.0).astype(np.float32)
     gs = rng.standard_normal((2, E, A, S)).astype(np.float32)
     dn = rng.random((2, E, A)) < 0.3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic build of the library with the per-phase cycle stamps (-DMAVA_STAMPS): tools/libmavahip_stamps.so, objects in /tmp.
-# Use with MAVA_LIB_PATH=tools/libmavahip_stamps.so (tools/train_stamps.py, tools/scratch/*_stamps.py).
+# Use with MAVA_LIB_PATH=tools/libmavahip_stamps.so (tools/train_stamps.py, tools/*_stamps.py).
 set -e
 cd "$(dirname "$0")/.."
 O=/tmp/mava_stamps_obj; mkdir -p $O

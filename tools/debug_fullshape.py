@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mava_amd import ops
-from mava_amd._lib import lib
+from mava_amd._lib import Ctx
 from oracle import ppo_oracle as po
 
 dev = torch.device("cuda", 0)
@@ -64,12 +64,11 @@ def seg_report(name, got, want, din_, no_):
     print(f"  {name}: " + "; ".join(out), flush=True)
 
 def run_critic(tag, idx_np, n_slab, agg, mode=0):
-    lib().mava_ppo_set_critic_aggregation(agg)
-    lib().mava_ppo_set_matmul_mode(mode)
+    ctx = Ctx("f16x2" if mode == 1 else "f32", critic_aggregation=bool(agg))
     idx_d = d(idx_np)
     slab = torch.zeros((n_slab, fc.size + 2), device=dev)
     out = torch.zeros(fc.size + 2, device=dev)
-    ops.ppo_critic_grad(fc_d, gs_d, A, ov_d, tg_d, idx_d, 0, Rb, A, 0.2, 0.5, slab)
+    ops.ppo_critic_grad(fc_d, gs_d, A, ov_d, tg_d, idx_d, 0, Rb, A, 0.2, 0.5, slab, ctx=ctx)
     ops.slab_reduce(slab, fc.size + 2, out)
     torch.cuda.synchronize()
     g = out.cpu().numpy()
@@ -79,22 +78,19 @@ def run_critic(tag, idx_np, n_slab, agg, mode=0):
     e3 = g[o3:o3 + 128] - acc_c[2][o3:o3 + 128]
     print(f"    dW3 signed error: mean {e3.mean():+.2e} rms {np.sqrt((e3 ** 2).mean()):.2e}  corr with mean-h2 proxy |want| {np.corrcoef(e3, acc_c[2][o3:o3 + 128])[0, 1]:+.2f};"
           f" db3 err {g[o3 + 128] - acc_c[2][o3 + 128]:+.2e} (want {acc_c[2][o3 + 128]:+.3e})")
-    lib().mava_ppo_set_critic_aggregation(1)
-    lib().mava_ppo_set_matmul_mode(0)
 
 def run_actor(tag, idx_np, n_slab, mode):
-    lib().mava_ppo_set_matmul_mode(mode)
+    ctx = Ctx("f16x2" if mode == 1 else "f32")
     idx_d = d(idx_np)
     slab = torch.zeros((n_slab, fa.size + 2), device=dev)
     out = torch.zeros(fa.size + 2, device=dev)
     stats = ops.adv_stats(adv_d, idx_d, 0, Rb, A)
-    ops.ppo_actor_grad(fa_d, av_d, mask_d, act_d, olp_d, adv_d, stats, idx_d, 0, Rb, A, nA, 0.2, 0.01, slab)
+    ops.ppo_actor_grad(fa_d, av_d, mask_d, act_d, olp_d, adv_d, stats, idx_d, 0, Rb, A, nA, 0.2, 0.01, slab, ctx=ctx)
     ops.slab_reduce(slab, fa.size + 2, out)
     torch.cuda.synchronize()
     g = out.cpu().numpy()
     print(f"[actor {tag}] loss got {g[fa.size]:.9f} want {acc_a[1]:.9f}; entropy got {g[fa.size + 1]:.9f} want {acc_a[2]:.9f}")
     seg_report(tag, g[:fa.size], acc_a[3], din, nA)
-    lib().mava_ppo_set_matmul_mode(0)
 
 run_critic("f32 agg 256 slabs", idx, 256, 1)
 run_critic("f16x2 agg 256 slabs", idx, 256, 1, mode=1)

@@ -1,4 +1,4 @@
-"""Times the GAE kernel variants (mava_gae_set_variant) with HIP events around a captured HIP graph of
+"""Times the GAE kernel variants (MAVA_CTX_GAE_VARIANT of a context handle) with HIP events around a captured HIP graph of
 back-to-back launches, so the host launch path (Python + ctypes, ~10 us) is not what is measured.
 
  warm: every launch re-reads the same 35.7 MB (served by L2 / the 256 MB infinity cache)
@@ -10,7 +10,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mava_amd import ops
-from mava_amd._lib import lib
+from mava_amd._lib import Ctx, lib
 
 T = 128
 REPS = 32
@@ -54,12 +54,12 @@ for N in sizes:
         t = graph_time(lambda i: dsts[i].copy_(srcs[i]), ns)
         print(f"copy of equal traffic [{mode}]: {t:6.2f} us -> {bytes_/t/1e3:7.1f} GB/s")
     for variant in variants:
-        lib().mava_gae_set_variant(variant)
+        ctx = Ctx()
+        ctx.set(ctx.GAE_VARIANT, variant)
         def run(i):
             r, v, d, lv, adv, tgt = sets[i]
-            ops.gae(r, v, d, lv, 0.99, 0.95, out=(adv, tgt))
+            ops.gae(r, v, d, lv, 0.99, 0.95, out=(adv, tgt), ctx=ctx)
         tw = graph_time(run, 1)
         tc = graph_time(run, n_cold)
         print(f"variant {variant:2d}: warm {tw:6.2f} us -> {bytes_/tw/1e3:7.1f} GB/s   cold {tc:6.2f} us -> {bytes_/tc/1e3:7.1f} GB/s ({bytes_/tc/1e3/80:.0f} % of 8 TB/s)")
     del sets, srcs, dsts
-lib().mava_gae_set_variant(0)

@@ -1,10 +1,9 @@
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mava_amd._lib import check, lib, ptr, stream_ptr
 dev = torch.device("cuda", 0)
 L = lib()
-L.mava_ppo_set_matmul_mode(1)
 L.mava_debug_set_out_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(8, dtype=torch.int64, device=dev)
 L.mava_debug_set_out_stamps(stamps.data_ptr())

@@ -5,7 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mava_amd import ops
-from mava_amd._lib import lib
+from mava_amd._lib import Ctx, lib
 
 dev = torch.device("cuda", 0)
 E, A, O, nA = 4096, 4, 66, 5
@@ -37,13 +37,13 @@ def graph_time(fn):
 
 
 for variant in (0, 1, 2):
-    lib().mava_policy_set_variant(variant)
+    ctx = Ctx()
+    ctx.set(ctx.POLICY_VARIANT, variant)
     for name, kw in (("critic per agent row", dict(critic_share=A, critic_rows=EA, value_broadcast=1)),
                      ("critic per env row", dict(critic_share=1, critic_rows=E, value_broadcast=A)),
                      ("actor only", dict(critic_share=1, critic_rows=0, value_broadcast=A))):
         o = (out[0], out[1], out[2][:0]) if kw["critic_rows"] == 0 else out
-        t = graph_time(lambda: ops.policy_step(pa, pc, av, mask, gs, n_actions=nA, seed=1, step=3, out=o, **kw))
+        t = graph_time(lambda: ops.policy_step(pa, pc, av, mask, gs, n_actions=nA, seed=1, step=3, out=o, ctx=ctx, **kw))
         print(f"variant {variant} {name:22s}: {t:6.1f} us")
-    t = graph_time(lambda: ops.mlp_forward(pc, A * O, 1, gs, rows=E, x_share=1))
+    t = graph_time(lambda: ops.mlp_forward(pc, A * O, 1, gs, rows=E, x_share=1, ctx=ctx))
     print(f"variant {variant} value only (E rows)   : {t:6.1f} us")
-lib().mava_policy_set_variant(0)

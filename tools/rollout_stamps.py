@@ -1,7 +1,7 @@
 """Diagnostic: per-phase cycles of the fused rollout kernel (library built by tools/build_stamps.sh, MAVA_LIB_PATH).
 Prints cycles per env step for wave 0 of the actor role and of the critic role of block 0."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mava_amd import envs
 from mava_amd._lib import lib

@@ -1,10 +1,10 @@
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from mava_amd._lib import check, lib, ptr, stream_ptr
+from mava_amd._lib import Ctx, check, lib, ptr, stream_ptr
 dev = torch.device("cuda", 0)
 L = lib()
-L.mava_ppo_set_matmul_mode(1)
+CTX = Ctx("f16x2")
 L.mava_debug_set_scan_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(8, dtype=torch.int64, device=dev)
 L.mava_debug_set_scan_stamps(stamps.data_ptr())
@@ -17,7 +17,7 @@ for Rm, A in ((8192, 8), (1024, 1)):
     idx = torch.randperm(E, device=dev)[: Rm // A].to(torch.int32).contiguous()
     done = (torch.rand((T, E, A), device=dev) < 0.02).to(torch.uint8)
     h0 = torch.zeros((E, A, 128), device=dev)
-    run = lambda: check(L.mava_gru_scan_fwd_f32(T, Rm, E, A, ptr(idx), ptr(done), ptr(h0), 0, ptr(wh), ptr(bhn), ptr(gi), ptr(hs), ptr(hprev), ptr(saved), stream_ptr()), "scan")
+    run = lambda: check(L.mava_gru_scan_fwd_f32(CTX.handle, T, Rm, E, A, ptr(idx), ptr(done), ptr(h0), 0, ptr(wh), ptr(bhn), ptr(gi), ptr(hs), ptr(hprev), ptr(saved), stream_ptr()), "scan")
     for _ in range(2): run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,7 +35,7 @@ for Rm, A in ((8192, 8), (1024, 1)):
     wh = torch.randn(128 * 384, device=dev) * 0.1
     idx = torch.randperm(E, device=dev)[: Rm // A].to(torch.int32).contiguous()
     done = (torch.rand((T, E, A), device=dev) < 0.02).to(torch.uint8)
-    run = lambda: check(L.mava_gru_scan_bwd_f32(T, Rm, E, A, ptr(idx), ptr(done), ptr(wh), ptr(saved), ptr(hprev), ptr(dh), ptr(dgi), ptr(dgh), stream_ptr()), "scanb")
+    run = lambda: check(L.mava_gru_scan_bwd_f32(CTX.handle, T, Rm, E, A, ptr(idx), ptr(done), ptr(wh), ptr(saved), ptr(hprev), ptr(dh), ptr(dgi), ptr(dgh), stream_ptr()), "scanb")
     for _ in range(2): run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mava_amd._lib import check, lib, ptr, stream_ptr
 dev = torch.device("cuda", 0)

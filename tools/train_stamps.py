@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mava_amd import ops
-from mava_amd._lib import lib
+from mava_amd._lib import Ctx, lib
 
 dev = torch.device("cuda", 0)
 MODE = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f16x2") else 0
@@ -18,7 +18,7 @@ if MODE == 1:  # phases of ppo_train_h2.hip
     names = ["P1 mfma", "P1 relu+image", "gather issue", "barrier A", "P2 mfma", "P2 image+head", "barrier B", "P3 loss",
              "B2+dz2+image", "barrier C", "P4 mfma+dz1+commit", "gW3+gW2", "barrier D", "gW1 (wide chain: gW2)", "loop top", "barrier B2"]
 l = lib()
-l.mava_ppo_set_matmul_mode(MODE)
+ctx = Ctx("f16x2" if MODE == 1 else "f32")
 l.mava_debug_set_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(128, dtype=torch.int64, device=dev)  # waves 0-3 (chain / only group), 4-7 (loader group of wide launches)
 l.mava_debug_set_stamps(stamps.data_ptr())
@@ -30,7 +30,7 @@ for which in ("critic", "actor"):
         x = torch.randn(TE, din, device=dev)
         ov, tg = torch.randn(TE * A, device=dev), torch.randn(TE * A, device=dev)
         slab = torch.zeros(256, params.numel() + 2, device=dev)
-        run = lambda: ops.ppo_critic_grad(params, x, A, ov, tg, perm, 0, Rb, A, 0.2, 0.5, slab)
+        run = lambda: ops.ppo_critic_grad(params, x, A, ov, tg, perm, 0, Rb, A, 0.2, 0.5, slab, ctx=ctx)
     else:
         din = A + O
         params = torch.randn(ops.mlp_param_count(din, nA), device=dev) * 0.05
@@ -40,7 +40,7 @@ for which in ("critic", "actor"):
         olp, adv = -torch.rand(TE * A, device=dev) - 1.0, torch.randn(TE * A, device=dev)
         st = ops.adv_stats(adv, perm, 0, Rb, A)
         slab = torch.zeros(256, params.numel() + 2, device=dev)
-        run = lambda: ops.ppo_actor_grad(params, x, mask, act, olp, adv, st, perm, 0, Rb, A, nA, 0.2, 0.01, slab)
+        run = lambda: ops.ppo_actor_grad(params, x, mask, act, olp, adv, st, perm, 0, Rb, A, nA, 0.2, 0.01, slab, ctx=ctx)
     for _ in range(2):
         run()
     torch.cuda.synchronize()

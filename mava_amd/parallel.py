@@ -64,6 +64,16 @@ class AbiComm:
         idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._h = C.c_void_p()
         check(self._lib.mava_comm_create(C.byref(self._h), rank, world, idb), "mava_comm_create")
+        # the communicator is torn down with the process at the latest (mava_comm_destroy: ncclCommDestroy)
+        import atexit
+
+        atexit.register(self._close_quietly)
+
+    def _close_quietly(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def allreduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         from ._lib import stream_ptr

@@ -293,7 +293,10 @@ def _traj(rng, TE, A, O, nA, shared_gs=True):
 @pytest.mark.parametrize("TE,A,O,nA,Rb,use_idx,n_slab", [(64, 4, 66, 5, 64, False, 3), (200, 4, 66, 5, 77, True, 8),
                                                           (96, 2, 30, 14, 40, True, 2), (33, 1, 7, 3, 33, True, 1),
                                                           (4096, 4, 66, 5, 2048, True, 256),
-                                                          (4096, 4, 66, 5, 4096, True, 16)])  # 32 tiles per block
+                                                          (4096, 4, 66, 5, 4096, True, 16),  # 32 tiles per block
+                                                          # the slab count of multi-rank jobs (system.rccl_cus = 8 CUs left
+                                                          # to RCCL: 248 persistent blocks), 1024 tiles dealt unevenly
+                                                          (9000, 4, 66, 5, 8192, True, 248)])
 def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmul_mode):
     from mava_amd import ops
     from oracle import torch_ref
@@ -341,7 +344,8 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmu
                                                              (4096, 4, 66, 2048, True, True, 256),
                                                              (150, 8, 20, 101, True, True, 5), (70, 2, 50, 70, False, True, 4),
                                                              (4096, 4, 66, 4096, True, True, 16),  # 8 / 32 tiles per block
-                                                             (2048, 4, 66, 2048, True, True, 4)])
+                                                             (2048, 4, 66, 2048, True, True, 4),
+                                                             (9000, 4, 66, 8192, True, True, 248)])  # rccl_cus = 8: 248 slabs
 @pytest.mark.parametrize("agg", [1, 0])
 def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, agg, matmul_mode):
     """agg=1: agents that share one critic input row are aggregated (one network pass per (t,e) row, the sum of

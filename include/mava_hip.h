@@ -45,7 +45,10 @@ enum {
                                       gradients back-propagated - the same gradient as A identical passes; 0: one pass per agent */
   MAVA_CTX_GAE_VARIANT = 2,        /* bench sweeps (tools/gae_sweep.py): chunk / lane mapping of mava_gae_f32, 0 = default */
   MAVA_CTX_POLICY_VARIANT = 3,     /* 0 = per-wave acting kernel / hybrid launch (default), 1 = per-wave only, 2 = block-cooperative */
-  MAVA_CTX_H2_LAUNCHES = 4         /* diagnostic counter: gradient launches of this handle that ran on the f16x2 kernels */
+  MAVA_CTX_H2_LAUNCHES = 4,        /* diagnostic counter: gradient launches of this handle that ran on the f16x2 kernels */
+  MAVA_CTX_TRAIN_VARIANT = 5,      /* f16x2 gradient kernels: 0 (default) = the eight-wave actor kernel (ppo_train_w8.hip) where it is
+                                      instantiated, 1 = the four-wave kernels (ppo_train_h2.hip) only; for A/B measurements */
+  MAVA_CTX_W8_LAUNCHES = 6         /* diagnostic counter: ... of which on the eight-wave kernel */
 };
 int mava_ctx_create(mava_ctx** out);
 int mava_ctx_destroy(mava_ctx* ctx); /* frees the handle's workspaces; NULL is a no-op */

@@ -124,7 +124,7 @@ class Ctx:
     settings: two Ctx objects (two learners in one process) share nothing.  `handle` is what the entry points take as
     their first argument (None = the library defaults: exact f32)."""
 
-    MATMUL_MODE, CRITIC_AGGREGATION, GAE_VARIANT, POLICY_VARIANT, H2_LAUNCHES = 0, 1, 2, 3, 4
+    MATMUL_MODE, CRITIC_AGGREGATION, GAE_VARIANT, POLICY_VARIANT, H2_LAUNCHES, TRAIN_VARIANT, W8_LAUNCHES = 0, 1, 2, 3, 4, 5, 6
 
     def __init__(self, matmul_mode: str = "f32", critic_aggregation: bool = True):
         if matmul_mode not in ("f32", "f16x2"):

@@ -24,6 +24,7 @@ HIP_SOURCES = [
     "mlp_coop.hip",
     "ppo_train.hip",
     "ppo_train_h2.hip",
+    "ppo_train_w8.hip",
     "rollout_h2.hip",
     "synth_rware.hip",
     "rec_dense.hip",

@@ -20,7 +20,7 @@ extern "C" const char* mava_last_error(void) { return g_err; }
 extern "C" int mava_abi_version(void) { return 3; }  // 3: round-3 signatures (mava_ctx handle instead of process-wide setters)
 
 // ---- context handle (ctx.h) -------------------------------------------------------------------------------------------
-enum { CTX_MATMUL_MODE = 0, CTX_CRITIC_AGGREGATION = 1, CTX_GAE_VARIANT = 2, CTX_POLICY_VARIANT = 3, CTX_H2_LAUNCHES = 4 };
+enum { CTX_MATMUL_MODE = 0, CTX_CRITIC_AGGREGATION = 1, CTX_GAE_VARIANT = 2, CTX_POLICY_VARIANT = 3, CTX_H2_LAUNCHES = 4, CTX_TRAIN_VARIANT = 5, CTX_W8_LAUNCHES = 6 };
 
 extern "C" int mava_ctx_create(mava_ctx** out) {
   MAVA_ARG_CHECK(out != nullptr, 0, "mava_ctx_create: null output pointer");
@@ -30,6 +30,8 @@ extern "C" int mava_ctx_create(mava_ctx** out) {
   c->gae_variant = 0;
   c->policy_variant = 0;
   c->h2_launches = 0;
+  c->train_variant = 0;
+  c->w8_launches = 0;
   c->w1_split[0] = c->w1_split[1] = nullptr;
   *out = c;
   return MAVA_OK;
@@ -54,6 +56,8 @@ extern "C" int mava_ctx_set(mava_ctx* c, int key, long value) {
     case CTX_GAE_VARIANT: c->gae_variant = (int)value; return MAVA_OK;
     case CTX_POLICY_VARIANT: c->policy_variant = (int)value; return MAVA_OK;
     case CTX_H2_LAUNCHES: c->h2_launches = value; return MAVA_OK;
+    case CTX_TRAIN_VARIANT: c->train_variant = (int)value; return MAVA_OK;
+    case CTX_W8_LAUNCHES: c->w8_launches = value; return MAVA_OK;
     default: mava_set_error("mava_ctx_set: unknown key %d", key); return MAVA_EARG(2);
   }
 }
@@ -66,6 +70,8 @@ extern "C" int mava_ctx_get(const mava_ctx* c, int key, long* value) {
     case CTX_GAE_VARIANT: *value = c->gae_variant; return MAVA_OK;
     case CTX_POLICY_VARIANT: *value = c->policy_variant; return MAVA_OK;
     case CTX_H2_LAUNCHES: *value = c->h2_launches; return MAVA_OK;
+    case CTX_TRAIN_VARIANT: *value = c->train_variant; return MAVA_OK;
+    case CTX_W8_LAUNCHES: *value = c->w8_launches; return MAVA_OK;
     default: mava_set_error("mava_ctx_get: unknown key %d", key); return MAVA_EARG(2);
   }
 }

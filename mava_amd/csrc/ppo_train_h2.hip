@@ -1066,6 +1066,13 @@ static int h2_dispatch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool acto
 // (ctx is never NULL here: a NULL handle means exact f32 and does not reach this file.)  h2_launches counts the launches
 // that really ran on the split-f16 kernel (mava_ctx_get(ctx, MAVA_CTX_H2_LAUNCHES): the parity tests assert it).
 int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
+  if (actor && ctx->train_variant == 0) {
+    const int rc8 = mava_train_w8_launch(tk, n_slab, s);
+    if (rc8 <= 0) {
+      if (rc8 == 0) { ++ctx->h2_launches; ++ctx->w8_launches; }
+      return rc8;
+    }
+  }
   const int rc = h2_dispatch(ctx, tk, n_slab, actor, s);
   if (rc == 0) ++ctx->h2_launches;
   return rc;

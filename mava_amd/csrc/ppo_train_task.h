@@ -34,4 +34,7 @@ struct TrainTask {
 // (hi + lo, f32 accumulation).  Returns MAVA_OK, or 1 when the shape is not instantiated (the caller then runs the
 // exact-f32 kernel), or a negative error code.
 struct mava_ctx;
+// ppo_train_w8.hip: the discrete actor's kernel on eight waves (two per SIMD, 16 features per wave, 16x16x32 MFMAs); same
+// return convention.  Tried first by mava_train_h2_launch unless the handle's MAVA_CTX_TRAIN_VARIANT is 1.
+int mava_train_w8_launch(const TrainTask& tk, int n_slab, hipStream_t s);
 int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s);

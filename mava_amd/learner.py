@@ -189,6 +189,8 @@ class FFLearner:
         # the library keeps no process-wide settings: arithmetic mode, critic aggregation and the kernels' own workspaces
         # belong to this learner's context handle (include/mava_hip.h mava_ctx_*)
         self.ctx = ops.Ctx(self.matmul_mode, critic_aggregation=os.environ.get("MAVA_CRITIC_AGGREGATION", "1") != "0")
+        # MAVA_TRAIN_VARIANT=1: the four-wave gradient kernels only (A/B measurements against the eight-wave actor kernel)
+        self.ctx.set(self.ctx.TRAIN_VARIANT, int(os.environ.get("MAVA_TRAIN_VARIANT", "0")))
         for net_ in (self.actor_network, self.critic_network):
             net_.ctx = self.ctx
         # the whole rollout in one launch (rollout_h2.hip) when the shape is instantiated; MAVA_FUSED_ROLLOUT=0 keeps
@@ -429,7 +431,7 @@ class FFLearner:
             else:
                 self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
                             rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base,
-                            self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a)
+                            self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a, ctx=self.ctx)
             ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
         # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
         # the critic's backward kernels run on this one

@@ -264,16 +264,31 @@ def test_policy_sampling_distribution(dev):
 
 
 # ---------------------------------------------------------------------------- PPO gradient kernels
-@pytest.fixture(params=[0, 1], ids=["f32", "f16x2"])
+@pytest.fixture(params=[0, 1, 2], ids=["f32", "f16x2", "f16x2-w4"])
 def matmul_mode(request):
     """0: exact-f32 MFMA kernels (ppo_train.hip); 1: split-f16 operands (ppo_train_h2.hip) for the shapes it
     instantiates (others fall back to the exact kernel).  Yields (mode, launches-on-the-f16x2-kernel counter, the context
     handle that carries the mode: the library has no process-wide setting)."""
     from mava_amd._lib import Ctx
 
-    ctx = Ctx("f16x2" if request.param == 1 else "f32")
-    yield request.param, (lambda: ctx.h2_launches), ctx
+    ctx = Ctx("f16x2" if request.param >= 1 else "f32")
+    if request.param == 2:  # the four-wave kernels only (ppo_train_h2.hip); default: the eight-wave actor kernel where instantiated
+        ctx.set(ctx.TRAIN_VARIANT, 1)
+    yield min(request.param, 1), (lambda: ctx.h2_launches), ctx
     ctx.close()
+
+
+def _kink_free(rng, flat, din, no, x_rows, TE, per_index, Rb, margin=5e-5):
+    """Rb of the TE (t,e) indices, none of which has a hidden pre-activation within `margin` of zero in the float64 network
+    `flat` on its `per_index` input rows: at >= 10^4 rows a few of the ~10^7 pre-activations sit closer to the ReLU kink
+    than the arithmetic's own rounding, f32 and f64 then legitimately take different branches, and one such unit moves
+    ~330 gradient entries by a whole row's contribution (see test_train_kernels_full_launch_shape)."""
+    _, (_, z1, _, z2, _) = po.mlp_forward(po.mlp_unflatten(flat.astype(np.float64), din, no), x_rows.astype(np.float64), keep=True)
+    near = (np.minimum(np.abs(z1).min(1), np.abs(z2).min(1)) < margin).reshape(TE, per_index).any(1)
+    cand = rng.permutation(TE)
+    cand = cand[~near[cand]]
+    assert cand.size >= Rb, "not enough kink-free rows"
+    return cand[:Rb].astype(np.int32)
 
 
 def _traj(rng, TE, A, O, nA, shared_gs=True):
@@ -306,7 +321,7 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmu
     din = O + A
     flat = _net(rng, din, nA, 1.0).astype(np.float32)
     if use_idx:
-        idx = rng.permutation(TE)[:Rb].astype(np.int32)
+        idx = rng.permutation(TE)[:Rb].astype(np.int32) if Rb < 8192 else _kink_free(rng, flat, din, nA, av, TE, A, Rb)
         base = 0
     else:
         idx = np.arange(Rb, dtype=np.int32)
@@ -337,6 +352,9 @@ def test_actor_grad_matches_oracle(dev, TE, A, O, nA, Rb, use_idx, n_slab, matmu
     assert_close(got[P:], np.array([la, ent]), 1e-5, "actor loss/entropy", scale=1.0)
     if matmul_mode[0] == 1:
         assert matmul_mode[1]() == 1, "the f16x2 kernel did not run for this shape"
+        ctx = matmul_mode[2]
+        want_w8 = ctx.get(ctx.TRAIN_VARIANT) == 0 and din + 1 <= 128 and nA <= 16
+        assert ctx.get(ctx.W8_LAUNCHES) == (1 if want_w8 else 0), "eight-wave / four-wave kernel selection"
 
 
 @pytest.mark.parametrize("TE,A,O,Rb,use_idx,shared,n_slab", [(64, 4, 66, 64, False, True, 3), (200, 4, 66, 77, True, True, 8),
@@ -357,6 +375,8 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
 
     if agg == 0 and not shared:
         pytest.skip("aggregation only applies to shared critic inputs")
+    if matmul_mode[2].get(matmul_mode[2].TRAIN_VARIANT) == 1:
+        pytest.skip("the kernel variant only concerns the actor")
     matmul_mode[2].set(matmul_mode[2].CRITIC_AGGREGATION, agg)
 
     rng = np.random.default_rng(TE + O)
@@ -364,6 +384,8 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
     din = A * O
     flat = _net(rng, din, 1, 1.0).astype(np.float32)
     idx = rng.permutation(TE)[:Rb].astype(np.int32) if use_idx else np.arange(Rb, dtype=np.int32)
+    if use_idx and Rb >= 8192:
+        idx = _kink_free(rng, flat, din, 1, gs, TE, 1 if shared else A, Rb)
     rows_sel = (idx[:, None].astype(np.int64) * A + np.arange(A)).reshape(-1)
     share = A if shared else 1
     xsel = gs[rows_sel // share]

@@ -204,10 +204,19 @@ def _check_traj(L, ora, n, ftol, max_flips=4):
         assert (margin[diff] < 1e-3).all(), f"sampled actions differ beyond a near-tie: margins {margin[diff]}"
         assert np.array_equal(rep.done.cpu().numpy().astype(bool), tr["done"])
         assert np.array_equal(rep.reward.cpu().numpy(), tr["reward"].astype(np.float32))
-        assert np.array_equal(rep.agents_view[: L.T].cpu().numpy(), tr["av"].astype(np.float32)), "recorded observations"
+        # recorded observations: slots 1 .. T-1 as the rollout wrote them; slot T is the bootstrap observation, which
+        # update() has already copied to slot 0 for the next rollout (slot 0's old content is gone) - both must equal the
+        # observation the oracle's env holds now
+        T_ = L.T
+        nxt = ora.obs[0][u]
+        assert np.array_equal(rep.agents_view[1:T_].cpu().numpy(), tr["av"][1:].astype(np.float32)), "recorded observations"
+        assert np.array_equal(rep.action_mask[1:T_].cpu().numpy().astype(bool), tr["mask"][1:].astype(bool))
+        for slot in (0, T_):
+            assert np.array_equal(rep.agents_view[slot].cpu().numpy(), nxt["agents_view"]), f"observation in slot {slot}"
+            assert np.array_equal(rep.action_mask[slot].cpu().numpy().astype(bool), nxt["action_mask"].astype(bool))
         if L.centralised:
-            assert np.array_equal(rep.global_state[: L.T, :, 0].cpu().numpy(), tr["cx"][:, :, 0].astype(np.float32)), "recorded state"
-        assert np.array_equal(rep.action_mask[: L.T].cpu().numpy().astype(bool), tr["mask"].astype(bool))
+            assert np.array_equal(rep.global_state[1:T_, :, 0].cpu().numpy(), tr["cx"][1:, :, 0].astype(np.float32)), "recorded state"
+            assert np.array_equal(rep.global_state[T_, :, 0].cpu().numpy(), nxt["global_state"][:, 0]), "bootstrap state"
         assert np.array_equal(rep.info_terminal[n].cpu().numpy().astype(bool), tr["term"])
         assert np.array_equal(rep.info_length[n].cpu().numpy(), tr["len"])
         assert np.array_equal(rep.info_return[n].cpu().numpy(), tr["ret"].astype(np.float32))

@@ -17,8 +17,14 @@ names = ["P1 layer1", "P2 layer2+head", "P3 loss+dz2", "P4 dh1+sweeps", "P4b dz1
 if MODE == 1:  # phases of ppo_train_h2.hip
     names = ["P1 mfma", "P1 relu+image", "gather issue", "barrier A", "P2 mfma", "P2 image+head", "barrier B", "P3 loss",
              "B2+dz2+image", "barrier C", "P4 mfma+dz1+commit", "gW3+gW2", "barrier D", "gW1 (wide chain: gW2)", "loop top", "barrier B2"]
+# phases of ppo_train_w8.hip (the eight-wave actor kernel, default for the discrete actor; `w4` as a second argument keeps
+# the four-wave kernel)
+names_w8 = ["P1 mfma", "P1 relu+image", "gather issue", "barrier A", "P2 mfma", "P2 image+head", "barrier B", "P3 loss | x commit",
+            "barrier B2", "gW3+dz2+image", "gW2", "barrier C", "dh1+dz1 image", "gW1", "loop top", "-"]
 l = lib()
 ctx = Ctx("f16x2" if MODE == 1 else "f32")
+if len(sys.argv) > 2 and sys.argv[2] == "w4":
+    ctx.set(ctx.TRAIN_VARIANT, 1)
 l.mava_debug_set_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(128, dtype=torch.int64, device=dev)  # waves 0-3 (chain / only group), 4-7 (loader group of wide launches)
 l.mava_debug_set_stamps(stamps.data_ptr())
@@ -41,12 +47,21 @@ for which in ("critic", "actor"):
         st = ops.adv_stats(adv, perm, 0, Rb, A)
         slab = torch.zeros(256, params.numel() + 2, device=dev)
         run = lambda: ops.ppo_actor_grad(params, x, mask, act, olp, adv, st, perm, 0, Rb, A, nA, 0.2, 0.01, slab, ctx=ctx)
+    w8_before = ctx.get(ctx.W8_LAUNCHES)
     for _ in range(2):
         run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); run(); b.record(); torch.cuda.synchronize()
     s8 = stamps.cpu().numpy().reshape(8, 16)
+    if ctx.get(ctx.W8_LAUNCHES) > w8_before:  # eight equal waves: print waves 0-3 and wave 4 (the SIMD partner of wave 0)
+        tot = s8.sum(1)
+        ntile = -(-(Rb * A) // 32 // 256)
+        print(f"== {which} (eight-wave kernel): launch {a.elapsed_time(b):.3f} ms, block 0 cycles per wave {tot.tolist()}, {ntile} tiles per block")
+        for i, n in enumerate(names_w8):
+            print(f"   {n:24s} " + "  ".join(f"{s8[w, i] / ntile:8.0f}" for w in (0, 1, 4, 5)) + f"   ({100 * s8[0, i] / tot[0]:5.1f} %)")
+        stamps.zero_()
+        continue
     s = s8[:4]
     tot = s.sum(1)
     # row tiles per block: agent rows for the actor; (t,e) rows for the critic when the agents of a row are aggregated

@@ -48,7 +48,10 @@ enum {
   MAVA_CTX_H2_LAUNCHES = 4,        /* diagnostic counter: gradient launches of this handle that ran on the f16x2 kernels */
   MAVA_CTX_TRAIN_VARIANT = 5,      /* f16x2 gradient kernels: 0 (default) = the eight-wave actor kernel (ppo_train_w8.hip) where it is
                                       instantiated, 1 = the four-wave kernels (ppo_train_h2.hip) only; for A/B measurements */
-  MAVA_CTX_W8_LAUNCHES = 6         /* diagnostic counter: ... of which on the eight-wave kernel */
+  MAVA_CTX_W8_LAUNCHES = 6,        /* diagnostic counter: ... of which on the eight-wave kernel */
+  MAVA_CTX_W1_SPLIT_FRESH = 7      /* read: 1 while the handle's pre-split W1 copy (wide f16x2 critic) already matches the parameters of
+                                      the next gradient launch (mava_ppo_finish_f32 wrote it); write 0: the caller changed parameters
+                                      by other means - the next launch re-splits them itself */
 };
 int mava_ctx_create(mava_ctx** out);
 int mava_ctx_destroy(mava_ctx* ctx); /* frees the handle's workspaces; NULL is a no-op */
@@ -82,6 +85,21 @@ int mava_clip_adam(float* p, const float* g, float* m, float* v, int32_t* count,
                    float max_norm, int decay, int steps_per_update, int num_updates, float b1,
                    float b2, float eps, const float* loss_sums, float vf_coef, float ent_coef,
                    float* metrics_out, mava_stream_t s);
+
+/* Tail of one minibatch on ONE rank with ONE update-batch replica (ff_mappo.py:224-266 with trivial pmeans) in two launches
+ * instead of six: (1) the fixed-order sums of BOTH networks' gradient slabs (slab_a rows [Pa grads | actor_loss, entropy],
+ * slab_c rows [Pc grads | value_loss]) into g = [actor | critic | actor_loss, entropy, value_loss, pad] - bit-identical to
+ * two mava_slab_reduce2_f32 calls - leaving each block's squared-norm partial in the workspace; (2) clip + Adam as
+ * mava_clip_adam (norms from those partials), the step-count increment and, through an arrival ticket, the re-split of a
+ * wide f16x2 critic's W1 (critic_din in [96, 287], handle in f16x2 mode; 0 = none) for the handle's next gradient launch by
+ * the block that finishes last.  workspace: mava_ppo_finish_workspace_bytes(Pa, Pc) bytes, 8-byte aligned, zeroed once by
+ * the caller and owned by this call sequence afterwards. */
+size_t mava_ppo_finish_workspace_bytes(int Pa, int Pc);
+int mava_ppo_finish_f32(mava_ctx* ctx, const float* slab_a, long stride_a, const float* slab_c, long stride_c, int n_slab,
+                        int Pa, int Pc, float* g, float* p, float* m, float* v, int32_t* count, float lr_a, float lr_c,
+                        float grad_scale, float max_norm, int decay, int steps_per_update, int num_updates, float b1,
+                        float b2, float eps, float vf_coef, float ent_coef, float* metrics_out, int critic_din,
+                        void* workspace, size_t workspace_bytes, mava_stream_t s);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_b slab[b*slab_stride + i], b ascending. */
 int mava_slab_reduce_f32(const float* slab, int n_slab, long slab_stride, int n, int accumulate,

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "mava_clip_adam": [vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, f32, f32, i32, i32, i32,
                        f32, f32, f32, vp, f32, f32, vp, vp],
     "mava_slab_reduce_f32": [vp, i32, lng, i32, i32, vp, vp],
+    "mava_ppo_finish_workspace_bytes": [i32, i32],
+    "mava_ppo_finish_f32": [vp, vp, lng, vp, lng, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, f32, f32, f32,
+                            f32, f32, vp, i32, vp, C.c_size_t, vp],
     "mava_slab_reduce2_f32": [vp, i32, lng, i32, vp, i32, vp, i32, vp],
     "mava_mlp_param_count": [i32, i32],
     "mava_mlp_forward_f32": [vp, vp, i32, i32, vp, i32, i32, vp, vp],
@@ -92,7 +95,7 @@ _SIGNATURES = {
     "mava_seq_sample_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_t32_convert_f32": [vp, i32, i32, i32, vp, vp],
 }
-_RESTYPES = {"mava_last_error": C.c_char_p, "mava_rec_step_pack_bytes": C.c_long}
+_RESTYPES = {"mava_last_error": C.c_char_p, "mava_rec_step_pack_bytes": C.c_long, "mava_ppo_finish_workspace_bytes": C.c_size_t}
 
 
 def declared_symbols():
@@ -114,7 +117,7 @@ def lib() -> C.CDLL:
         for name, args in _SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = _RESTYPES.get(name, C.c_int)
     return _lib
 
 
@@ -124,7 +127,7 @@ class Ctx:
     settings: two Ctx objects (two learners in one process) share nothing.  `handle` is what the entry points take as
     their first argument (None = the library defaults: exact f32)."""
 
-    MATMUL_MODE, CRITIC_AGGREGATION, GAE_VARIANT, POLICY_VARIANT, H2_LAUNCHES, TRAIN_VARIANT, W8_LAUNCHES = 0, 1, 2, 3, 4, 5, 6
+    MATMUL_MODE, CRITIC_AGGREGATION, GAE_VARIANT, POLICY_VARIANT, H2_LAUNCHES, TRAIN_VARIANT, W8_LAUNCHES, W1_SPLIT_FRESH = 0, 1, 2, 3, 4, 5, 6, 7
 
     def __init__(self, matmul_mode: str = "f32", critic_aggregation: bool = True):
         if matmul_mode not in ("f32", "f16x2"):

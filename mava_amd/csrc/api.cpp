@@ -20,7 +20,7 @@ extern "C" const char* mava_last_error(void) { return g_err; }
 extern "C" int mava_abi_version(void) { return 3; }  // 3: round-3 signatures (mava_ctx handle instead of process-wide setters)
 
 // ---- context handle (ctx.h) -------------------------------------------------------------------------------------------
-enum { CTX_MATMUL_MODE = 0, CTX_CRITIC_AGGREGATION = 1, CTX_GAE_VARIANT = 2, CTX_POLICY_VARIANT = 3, CTX_H2_LAUNCHES = 4, CTX_TRAIN_VARIANT = 5, CTX_W8_LAUNCHES = 6 };
+enum { CTX_MATMUL_MODE = 0, CTX_CRITIC_AGGREGATION = 1, CTX_GAE_VARIANT = 2, CTX_POLICY_VARIANT = 3, CTX_H2_LAUNCHES = 4, CTX_TRAIN_VARIANT = 5, CTX_W8_LAUNCHES = 6, CTX_W1_SPLIT_FRESH = 7 };
 
 extern "C" int mava_ctx_create(mava_ctx** out) {
   MAVA_ARG_CHECK(out != nullptr, 0, "mava_ctx_create: null output pointer");
@@ -33,6 +33,7 @@ extern "C" int mava_ctx_create(mava_ctx** out) {
   c->train_variant = 0;
   c->w8_launches = 0;
   c->w1_split[0] = c->w1_split[1] = nullptr;
+  c->w1_fresh[0] = c->w1_fresh[1] = 0;
   *out = c;
   return MAVA_OK;
 }
@@ -58,6 +59,10 @@ extern "C" int mava_ctx_set(mava_ctx* c, int key, long value) {
     case CTX_H2_LAUNCHES: c->h2_launches = value; return MAVA_OK;
     case CTX_TRAIN_VARIANT: c->train_variant = (int)value; return MAVA_OK;
     case CTX_W8_LAUNCHES: c->w8_launches = value; return MAVA_OK;
+    case CTX_W1_SPLIT_FRESH:
+      MAVA_ARG_CHECK(value == 0, 1, "mava_ctx_set: MAVA_CTX_W1_SPLIT_FRESH can only be cleared (0) by the caller");
+      c->w1_fresh[0] = c->w1_fresh[1] = 0;
+      return MAVA_OK;
     default: mava_set_error("mava_ctx_set: unknown key %d", key); return MAVA_EARG(2);
   }
 }
@@ -72,6 +77,7 @@ extern "C" int mava_ctx_get(const mava_ctx* c, int key, long* value) {
     case CTX_H2_LAUNCHES: *value = c->h2_launches; return MAVA_OK;
     case CTX_TRAIN_VARIANT: *value = c->train_variant; return MAVA_OK;
     case CTX_W8_LAUNCHES: *value = c->w8_launches; return MAVA_OK;
+    case CTX_W1_SPLIT_FRESH: *value = c->w1_fresh[1]; return MAVA_OK;
     default: mava_set_error("mava_ctx_get: unknown key %d", key); return MAVA_EARG(2);
   }
 }

@@ -15,6 +15,9 @@ struct mava_ctx {
   long h2_launches;        // diagnostic: gradient launches of this handle that ran on the f16x2 kernels
   long w8_launches;        // diagnostic: ... of which on the eight-wave kernel (ppo_train_w8.hip)
   void* w1_split[2];       // f16x2, inputs wider than 95: pre-split W1 in fragment order (actor, critic), lazily allocated
+  int w1_fresh[2];         // one-shot: the copy already matches the parameters of the NEXT gradient launch (written by the Adam
+                           // launch of mava_ppo_finish_f32); cleared by that launch, and by the caller whenever parameters may
+                           // have changed in between (MAVA_CTX_W1_SPLIT_FRESH)
 };
 
 static inline int mava_ctx_matmul_mode(const mava_ctx* c) { return c ? c->matmul_mode : 0; }

@@ -187,6 +187,33 @@ __device__ __forceinline__ void sw_write_image(u8* img, int r, int w, int h, con
   }
 }
 
+// Pre-split copy of a WIDE layer-1 weight matrix in fragment order for ppo_train_h2.hip's register ring:
+// out[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane); lane (r, h) of wave w holds W1[k = 16 s + 8 h + e][f = 32 w + r];
+// k == din is b1, k > din zero.  One 256-thread group (tid = 0..255): the error-diffusion carry of split1_carry runs
+// along k over each lane's own inputs, so the work is a chain of memory round trips - every load of the thread
+// (8 x STEPS <= 144 floats) is issued before the first is used: one round trip instead of one per few steps.
+template <int STEPS>
+__device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int din, uint4* __restrict__ out, int tid) {
+  const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  float v[STEPS][8];
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * i + 8 * h + e;
+      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+    }
+  float carry = 0.0f;
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+    const Frag f = split8_carry(v[i], carry);
+    const int gid = i * 256 + tid;
+    out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
+    out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
+  }
+}
+constexpr size_t W1_SPLIT_BYTES = (size_t)18 * 256 * 32;  // the largest instantiated layer (18 steps = 287 inputs + bias)
+
 // All-reduce over aligned groups of G consecutive lanes (G = 8, 16, 32) on the VALU's DPP path (as ppo_train.hip)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

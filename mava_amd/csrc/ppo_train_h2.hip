@@ -92,30 +92,11 @@ H2Layout make_h2_layout(bool actor) {
 constexpr int W2_PLANE = 128 * SW_ROW;  // (the images of this kernel are the swizzled ones of h2_core.h; regions keep IMG_BYTES)
 constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 is padded to a multiple of it)
 
-// WIDE: pre-split copy of W1 in fragment order, W1P[step s][wave w][lane] = {8 x hi, 8 x lo} (32 bytes per lane):
-// lane (r, h) of wave w holds W1[k = 16s + 8h + e][f = 32w + r]; k == din is b1, k > din zero.
+// WIDE: pre-split copy of W1 in fragment order (h2_core.h pack_w1_body), written by this kernel ahead of a launch - or by
+// the Adam kernel of the minibatch before it (adam.hip, mava_ppo_finish_f32), which then marks the handle's copy fresh.
 template <int STEPS>
 __global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, uint4* __restrict__ out) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  // one block (the error-diffusion carry of split1_carry runs along k over this lane's inputs of feature 32w + r), so the
-  // launch is a chain of memory round trips: every load of the thread (8 x STEPS <= 144 floats) is issued before the first
-  // is used - one round trip instead of one per six steps
-  float v[STEPS][8];
-#pragma unroll
-  for (int i = 0; i < STEPS; ++i)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 16 * i + 8 * h + e;
-      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
-    }
-  float carry = 0.0f;
-#pragma unroll
-  for (int i = 0; i < STEPS; ++i) {
-    const Frag f = split8_carry(v[i], carry);
-    const int gid = i * 256 + threadIdx.x;
-    out[2 * gid] = __builtin_bit_cast(uint4, f.hi);
-    out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
-  }
+  pack_w1_body<STEPS>(P, din, out, threadIdx.x);
 }
 
 // ROLE 0: one 4-wave group does everything (narrow inputs).  WIDE launches run 8 waves in two roles with disjoint register
@@ -1004,10 +985,14 @@ int launch_h2(mava_ctx* ctx, const TrainTask& tk, int n_slab, hipStream_t s) {
   const uint4* w1p = nullptr;
   if (WIDE) {
     void*& slot = ctx->w1_split[ACTOR ? 0 : 1];
-    if (slot == nullptr) MAVA_HIP_CHECK(hipMalloc(&slot, (size_t)18 * 256 * 32));
+    if (slot == nullptr) MAVA_HIP_CHECK(hipMalloc(&slot, W1_SPLIT_BYTES));
     uint4* const buf = static_cast<uint4*>(slot);
-    hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf);
-    MAVA_LAUNCH_CHECK();
+    int& fresh = ctx->w1_fresh[ACTOR ? 0 : 1];  // set by mava_ppo_finish_f32: its Adam launch has already re-split these weights
+    if (!fresh) {
+      hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf);
+      MAVA_LAUNCH_CHECK();
+    }
+    fresh = 0;
     w1p = buf;
   }
   hipLaunchKernelGGL((ppo_train_h2_kernel<NO, S1, ACTOR, WIDE, XV>), dim3(n_slab), dim3(WIDE ? 512 : 256), L.end, s, tk, L,

@@ -203,6 +203,11 @@ class FFLearner:
                               and int(getattr(env0, "synth_state_dim", 0)) == 0
                               and (not centralised_critic or (env0.gs_tiles == 1 and env0.global_state_shared)))
         self._learn_calls = 0  # guards.check_f16_range: the previous call's metrics are checked from the second call on
+        # One rank, one replica: nothing sits between the gradient kernels and Adam, so both slab sums, clip + Adam, the
+        # count increment and the wide critic's W1 re-split run as TWO launches (ops.ppo_finish) instead of six
+        self.fused_tail = (self.U == 1 and self.world == 1 and not self.generic
+                           and os.environ.get("MAVA_FUSED_TAIL", "1") != "0")
+        self._finish_ws = ops.ppo_finish_workspace(self.Pa, self.Pc, d) if self.fused_tail else None
 
     def _timed(self, name: str, fn, *args, **kwargs):
         """Run one kernel launch, optionally bracketed by HIP events on the launch stream."""
@@ -432,7 +437,8 @@ class FFLearner:
                 self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
                             rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base,
                             self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a, ctx=self.ctx)
-            ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
+            if not self.fused_tail:
+                ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
         # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
         # the critic's backward kernels run on this one
         w_actor = parallel.allreduce_sum_async(self.g[: self.Pa])
@@ -441,7 +447,16 @@ class FFLearner:
             cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
             self._timed("critic_grad", ops.ppo_critic_grad, pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA),
                         idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c, ctx=self.ctx)
-            ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=u > 0)
+            if not self.fused_tail:
+                ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=u > 0)
+        if self.fused_tail:
+            self._timed("finish", ops.ppo_finish, self.ctx, self.slab_a, self.slab_c, self.Pa, self.Pc, self.g, self.p, self.m, self.v,
+                        self.count, self.seg_lr[0], self.seg_lr[1], grad_scale=1.0, max_norm=float(s.max_grad_norm),
+                        decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
+                        num_updates=int(s.get("num_updates", 1) or 1), vf_coef=float(s.vf_coef), ent_coef=float(s.ent_coef),
+                        metrics_out=self.train_metrics[n, k, mb], critic_din=self.Oc, workspace=self._finish_ws)
+            self.ent_step += 1
+            return
         w_rest = parallel.allreduce_sum_async(self.g[self.Pa :])  # critic gradient + the loss scalars
         for wk in (w_actor, w_rest):
             if wk is not None:
@@ -561,6 +576,9 @@ class FFLearner:
         own = permutations is None
         if own:
             permutations = self._permutations()
+        # parameters may have been written from outside since the last minibatch (adopt(), a test): the first wide critic
+        # launch of an update always re-splits W1 itself (MAVA_CTX_W1_SPLIT_FRESH)
+        self.ctx.set(self.ctx.W1_SPLIT_FRESH, 0)
         self._rollout(n)
         # advantage statistics of ALL K x M minibatches in one launch per replica (the permutations are this learner's
         # own contiguous buffer: minibatch (k, mb) = slice k * M + mb of it); otherwise one launch per minibatch

@@ -584,3 +584,60 @@ def test_policy_kernels_both_variants(dev, variant):
     a = action.cpu().numpy()
     assert (a != a_or).mean() < 0.005
     assert_close(logp.cpu().numpy(), po.log_softmax(z)[np.arange(rows), a], 1e-5, "log_prob")
+
+
+@pytest.mark.parametrize("din_c,mode,big", [(264, "f16x2", True), (70, "f16x2", False), (264, "f32", False), (150, "f16x2", True)])
+def test_fused_tail_equals_separate_launches(dev, din_c, mode, big):
+    """mava_ppo_finish_f32 (both slab sums + clip + Adam + count increment in two launches, the wide critic's W1 re-split by
+    the last-arriving Adam block) against the six launches it replaces: the reduced gradient bit for bit, parameters and
+    moments to the last few ulps (the squared norm is summed in another fixed order), and - through the next critic launch -
+    the re-split W1 bit for bit equal to the stand-alone pack kernel's."""
+    from mava_amd import ops
+    from mava_amd._lib import Ctx
+
+    rng = np.random.default_rng(din_c)
+    din_a, nA, n_slab = 70, 5, 37
+    Pa, Pc = ops.mlp_param_count(din_a, nA), ops.mlp_param_count(din_c, 1)
+    P = Pa + Pc
+    scale = 3.0 if big else 1e-3  # clip active / inactive
+    slab_a = _t((rng.standard_normal((n_slab, Pa + 2)) * scale / n_slab).astype(np.float32), dev)
+    slab_c = _t((rng.standard_normal((n_slab, Pc + 2)) * scale / n_slab).astype(np.float32), dev)
+    p0 = (rng.standard_normal(P) * 0.1).astype(np.float32)
+    state = lambda: (_t(p0, dev), torch.zeros(P, device=dev), torch.zeros(P, device=dev), torch.zeros(2, dtype=torch.int32, device=dev))
+    kw = dict(max_norm=0.5, decay=True, steps_per_update=4, num_updates=10, vf_coef=0.5, ent_coef=0.01)
+    # reference: the separate launches
+    p1, m1, v1, c1 = state()
+    g1 = torch.zeros(P + 4, device=dev)
+    met1 = torch.zeros((3, 4), device=dev)
+    ctx = Ctx(mode)
+    p2, m2, v2, c2 = state()
+    g2 = torch.zeros(P + 4, device=dev)
+    met2 = torch.zeros((3, 4), device=dev)
+    ws = ops.ppo_finish_workspace(Pa, Pc, dev)
+    for step in range(3):  # (the arrival ticket must be ready again for the second and third launch)
+        ops.slab_reduce2(slab_a, Pa, g1[:Pa], 2, g1[P : P + 2])
+        ops.slab_reduce2(slab_c, Pc, g1[Pa:P], 1, g1[P + 2 : P + 3])
+        ops.clip_adam(p1, g1, m1, v1, c1, [0, Pa, P], [1e-3, 2e-3], grad_scale=1.0, loss_sums=g1[P:], metrics_out=met1[step], **kw)
+        ops.ppo_finish(ctx, slab_a, slab_c, Pa, Pc, g2, p2, m2, v2, c2, 1e-3, 2e-3, grad_scale=1.0, metrics_out=met2[step],
+                       critic_din=din_c, workspace=ws, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(g1[: P + 3], g2[: P + 3]), "reduced gradient / loss sums"
+        assert c1.tolist() == c2.tolist() == [step + 1, step + 1]
+        assert torch.equal(met1[step], met2[step])
+        for name, a, b in (("p", p1, p2), ("m", m1, m2), ("v", v1, v2)):
+            assert_close(b.cpu().numpy(), a.cpu().numpy(), 2e-6, f"{name} after step {step}")
+    wide = mode == "f16x2" and 96 <= din_c <= 287
+    assert ctx.get(ctx.W1_SPLIT_FRESH) == (1 if wide else 0)
+    if wide:
+        # the next critic launch of this handle reads the W1 copy the Adam launch wrote; a fresh handle packs it itself
+        TE, A, Rb = 64, 4, 64
+        gs = _t(rng.standard_normal((TE, din_c)).astype(np.float32), dev)
+        ov, tg = _t(rng.standard_normal(TE * A).astype(np.float32), dev), _t(rng.standard_normal(TE * A).astype(np.float32), dev)
+        outs = []
+        for c in (ctx, Ctx(mode)):
+            slab = torch.zeros((3, Pc + 2), device=dev)
+            ops.ppo_critic_grad(p2[Pa:], gs, A, ov, tg, None, 0, Rb, A, 0.2, 0.5, slab, ctx=c)
+            torch.cuda.synchronize()
+            outs.append(slab.clone())
+        assert ctx.get(ctx.W1_SPLIT_FRESH) == 0, "the fresh flag is one-shot"
+        assert torch.equal(outs[0], outs[1]), "critic gradient on the W1 copy re-split inside the Adam launch"

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_kernel(
     if constexpr (PACK > 0) {
       if (s_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' parameter stores, not this CU's cached lines
-        h2::pack_w1_body<PACK>(tail.pack_params, tail.pack_din, tail.w1_split, threadIdx.x);
+        h2::pack_w1_body<PACK>(tail.pack_params, tail.pack_din, tail.w1_split, threadIdx.x, h2::W_SCALE_CRITIC);
       }
     }
   }

@@ -192,8 +192,9 @@ __device__ __forceinline__ void sw_write_image(u8* img, int r, int w, int h, con
 // k == din is b1, k > din zero.  One 256-thread group (tid = 0..255): the error-diffusion carry of split1_carry runs
 // along k over each lane's own inputs, so the work is a chain of memory round trips - every load of the thread
 // (8 x STEPS <= 144 floats) is issued before the first is used: one round trip instead of one per few steps.
+// `scale` (a power of two): the weights are split as scale * w (the consumer unscales its f32 accumulator), see W_SCALE_CRITIC.
 template <int STEPS>
-__device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int din, uint4* __restrict__ out, int tid) {
+__device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int din, uint4* __restrict__ out, int tid, float scale) {
   const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   float v[STEPS][8];
 #pragma unroll
@@ -201,7 +202,7 @@ __device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int di
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 16 * i + 8 * h + e;
-      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] * scale : 0.0f;
     }
   float carry = 0.0f;
 #pragma unroll
@@ -212,6 +213,14 @@ __device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int di
     out[2 * gid + 1] = __builtin_bit_cast(uint4, f.lo);
   }
 }
+// The critic's W1 / W2 are split as 16 w.  A weight of magnitude ~0.1 has its low term (|w - hi| <= 2^-11 |w| ~ 4e-5) in
+// f16's SUBNORMAL range, whose spacing is an absolute 2^-24 = 6e-8: what hi + lo then fails to represent is ~2e-7 |w| - and it
+// is the same in every batch row, so with non-negative (post-ReLU) inputs it shifts the value coherently by ~1e-8, which
+// the value-loss gradient (entries that cancel to 1 / sqrt(rows) of their terms) shows at the full launch shape: dW3 entries at
+// 1.1 - 1.6 x the 1e-4 tolerance over five seeds where exact f32 sits at 0.2 - 0.9 (tools/debug_fullshape.py; the matrix pipe
+// keeps subnormal inputs and rounds a 16-product group once, without bias: tools/microbench/mfma_round_probe.hip).  Scaled by
+// 2^4 the low terms are normal numbers with their full 11 bits; the f32 accumulator is unscaled by an exact multiplication.
+constexpr float W_SCALE_CRITIC = 16.0f;
 constexpr size_t W1_SPLIT_BYTES = (size_t)18 * 256 * 32;  // the largest instantiated layer (18 steps = 287 inputs + bias)
 
 // All-reduce over aligned groups of G consecutive lanes (G = 8, 16, 32) on the VALU's DPP path (as ppo_train.hip)

@@ -95,8 +95,8 @@ constexpr int W1_RING = 3;  // WIDE: register ring depth in 16-input steps (S1 i
 // WIDE: pre-split copy of W1 in fragment order (h2_core.h pack_w1_body), written by this kernel ahead of a launch - or by
 // the Adam kernel of the minibatch before it (adam.hip, mava_ppo_finish_f32), which then marks the handle's copy fresh.
 template <int STEPS>
-__global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, uint4* __restrict__ out) {
-  pack_w1_body<STEPS>(P, din, out, threadIdx.x);
+__global__ __launch_bounds__(256) void pack_w1_kernel(const float* __restrict__ P, int din, uint4* __restrict__ out, float scale) {
+  pack_w1_body<STEPS>(P, din, out, threadIdx.x, scale);
 }
 
 // ROLE 0: one 4-wave group does everything (narrow inputs).  WIDE launches run 8 waves in two roles with disjoint register
@@ -119,6 +119,8 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   constexpr bool W2_RES4 = false;
 #endif
   constexpr int NTHR = WIDE ? 512 : 256;
+  // the critic's weights are split as WS * w, its layer accumulators unscaled by WU (h2_core.h W_SCALE_CRITIC); actor: 1
+  constexpr float WS = ACTOR ? 1.0f : W_SCALE_CRITIC, WU = 1.0f / WS;
   constexpr int KT1 = (S1 + 1) / 2;  // 32-input tiles of the layer-1 weight gradient
   u8* const H1I = lds + L.h1;
   u8* const DZ2I = lds + L.dz2;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll 8
       for (int k = k0; k < k0 + 64; ++k) {
         _Float16 x0, x1;
-        split1_carry(P[oW2 + k * MLP_H + n], carry, x0, x1);
+        split1_carry(P[oW2 + k * MLP_H + n] * WS, carry, x0, x1);
         const int o = sw_off(k, n >> 3) + 2 * (n & 7);
         *reinterpret_cast<_Float16*>(W2I + o) = x0;
         *reinterpret_cast<_Float16*>(W2I + W2_PLANE + o) = x1;
@@ -215,7 +217,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 16 * s + 8 * h + e;
-        v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] : 0.0f;
+        v[e] = (k <= din) ? P[k * MLP_H + 32 * w + r] * WS : 0.0f;
       }
       W1f[s] = split8_carry(v, w1_carry);
     }
@@ -498,7 +500,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     STAMP(0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      acc[q] = fmaxf(acc[q], 0.0f);
+      acc[q] = fmaxf(ACTOR ? acc[q] : acc[q] * WU, 0.0f);
       relu1 |= (acc[q] > 0.0f) ? (1u << q) : 0u;
     }
     {
@@ -565,7 +567,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     uint32_t relu2 = 0;
     if constexpr (CHAIN) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h];
+    for (int q = 0; q < 16; ++q) h2[q] = B2s[32 * w + (q & 3) + 8 * (q >> 2) + 4 * h] * WS;  // (unscaled with the products below)
     {
       Frag an;
       if constexpr (!W2_RESIDENT) an = sw_read_tr(W2I, W2_PLANE, trS, 0, w);  // W2[16s+8h+e][32w+r]
@@ -584,7 +586,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     STAMP(4);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      h2[q] = fmaxf(h2[q], 0.0f);
+      h2[q] = fmaxf(ACTOR ? h2[q] : h2[q] * WU, 0.0f);
       relu2 |= (h2[q] > 0.0f) ? (1u << q) : 0u;
     }
     if (!ACTOR) {
@@ -813,7 +815,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? acc[q] : 0.0f;
+      for (int q = 0; q < 16; ++q) acc[q] = ((relu1 >> q) & 1u) ? (ACTOR ? acc[q] : acc[q] * WU) : 0.0f;
       half4 ph[4], pl[4];
       sw_write_image(DZ1I, r, w, h, acc, ph, pl);
     }
@@ -989,7 +991,7 @@ int launch_h2(mava_ctx* ctx, const TrainTask& tk, int n_slab, hipStream_t s) {
     uint4* const buf = static_cast<uint4*>(slot);
     int& fresh = ctx->w1_fresh[ACTOR ? 0 : 1];  // set by mava_ppo_finish_f32: its Adam launch has already re-split these weights
     if (!fresh) {
-      hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf);
+      hipLaunchKernelGGL((pack_w1_kernel<S1>), dim3(1), dim3(256), 0, s, tk.params, tk.din, buf, ACTOR ? 1.0f : W_SCALE_CRITIC);
       MAVA_LAUNCH_CHECK();
     }
     fresh = 0;

@@ -513,3 +513,45 @@ def test_two_learners_with_different_arithmetic_share_nothing(dev):
     assert torch.equal(la.learner.p, solo["f16x2"]) and torch.equal(lb.learner.p, solo["f32"])
     assert not torch.equal(solo["f16x2"], solo["f32"])
     assert la.learner.ctx.h2_launches == 3 * 2 * 2 * 2 and lb.learner.ctx.h2_launches == 0
+
+
+def test_f16x2_free_running_drift(dev):
+    """The default arithmetic against exact f32 over TEN updates with NO re-synchronisation: two learners from the same
+    seeds (same initial parameters, same env streams, same action noise, same epoch permutations), one on the f16x2
+    kernels with the one-launch rollout, one on the exact-f32 kernels with the per-step rollout.  Their sampled actions
+    agree except on near-ties of the Gumbel-max, so the trajectories stay (almost) the same data and the parameter distance
+    measures how the ~22-bit operands compound through Adam: it must stay small and grow smoothly - a number, not a hope.
+    Printed for the record (profiles/r03_f16x2_drift.txt holds one run)."""
+    from mava_amd import envs
+    from mava_amd.systems.ppo import ff_mappo
+
+    E, A, T, K, M, N = 64, 4, 32, 2, 2, 10
+    learners = {}
+    for mm in ("f16x2", "f32"):
+        cfg = _cfg("ff_mappo", A, E, T, K, M, 1)
+        cfg.system.matmul_mode = mm
+        cfg.system.num_updates_per_eval = 1
+        cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 1e-3  # 4x Mava's default step: drift shows earlier
+        cfg.env.kwargs.time_limit = 20
+        env, _ = envs.make(cfg, add_global_state=True, device=dev)
+        learn, _, state = ff_mappo.learner_setup(env, (42, 7, 8), cfg, device=dev)
+        learners[mm] = (learn, state)
+    la, lb = learners["f16x2"][0].learner, learners["f32"][0].learner
+    assert la.fused_rollout and not lb.fused_rollout and torch.equal(la.p, lb.p)
+    sa, sb = learners["f16x2"][1], learners["f32"][1]
+    dist, flips = [], []
+    for n in range(N):
+        sa = learners["f16x2"][0](sa).learner_state
+        sb = learners["f32"][0](sb).learner_state
+        torch.cuda.synchronize()
+        pa, pb = la.p.double(), lb.p.double()
+        dist.append(float((pa - pb).norm() / pb.norm()))
+        flips.append(float((la.reps[0].action != lb.reps[0].action).float().mean()))
+    print("\nf16x2 vs f32, free running: relative parameter distance per update " + " ".join(f"{d:.2e}" for d in dist)
+          + "; share of differing sampled actions " + " ".join(f"{f:.1e}" for f in flips))
+    assert all(np.isfinite(dist)) and dist[0] < 2e-5, dist
+    assert dist[-1] < 2e-3, f"parameters drifted apart: {dist}"
+    assert max(flips) < 5e-3, flips
+    # the losses of the last update agree far inside their own scale
+    ma, mb = la.train_metrics[0].cpu().numpy(), lb.train_metrics[0].cpu().numpy()
+    assert_close(ma, mb, 2e-3, "train metrics after ten free-running updates", scale=1.0)

@@ -104,9 +104,16 @@ inline W8Layout make_w8_layout() {
 // W2RES: the layer-2 forward operand (this wave's 16 columns of W2: 32 registers) stays in registers; otherwise it is read
 // from the W2 image with hardware-transposed reads (16 per tile and wave) - the default: with it resident the kernel
 // needs 271 registers and spills inside the tile loop.
-template <int NO, int S1, int XV, bool W2RES>
-__global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8Layout L) {
-  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+// ROLE: with 8 action lanes per row the loss occupies 256 threads, so the per-row duties are divided between the two wave
+// groups (separate functions: separate register sets): ROLE 1 = waves 0-3, the loss of the tile's 32 rows; ROLE 2 = waves 4-7,
+// the x staging (gather of the next tile's rows, split + commit into the other x buffer) - in the first version, where
+// every wave staged and waves 0-3 also ran the loss, waves 4-7 waited ~900 of a tile's 10.7 K cycles at barrier B2
+// (phase stamps).  ROLE 0 (16 action lanes: every thread is a loss lane) does both.  All roles run the same barrier sequence
+// and the same matrix work on their own 16 features.  (A static priority raise for waves 4-7, the younger half that loses
+// issue arbitration against its SIMD partners - s_setprio 1 - was measured: 65.5 M env-steps/s either way.)
+template <int NO, int S1, int XV, bool W2RES, int ROLE>
+__device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, u8* lds) {
+  constexpr bool DO_LOSS = ROLE != 2, DO_STAGE = ROLE != 1;
   constexpr int KT1 = 2 * S1;  // 16-input tiles of the layer-1 weight gradient
   u8* const H1I = lds + L.h1;
   u8* const DZ2I = lds + L.dz2;
@@ -208,13 +215,15 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
   float ab2[4] = {0, 0, 0, 0}, ab3 = 0.0f, loss_a = 0.0f, loss_b = 0.0f;
 
   // ---------------------------------------------------------------- rows: cursors, staging, loss inputs
-  constexpr int LOSS_THREADS = 32 * NO;   // one lane per (row, action slot)
-  const bool loss_thread = tid < LOSS_THREADS;  // wave-uniform (multiples of 64)
+  constexpr int LOSS_THREADS = 32 * NO;   // one lane per (row, action slot): threads [0, 32 NO)
+  static_assert(ROLE == 0 ? LOSS_THREADS == 512 : LOSS_THREADS == 256, "role split belongs to 8 action lanes");
   const int lrow = tid / NO, lo = tid & (NO - 1);
-  const int srow = tid >> 4, l16 = tid & 15;     // staging: 16 threads per row
+  constexpr int TPR = (ROLE == 2) ? 8 : 16;        // staging threads per row
+  const int st = (ROLE == 2) ? (tid - 256) : tid;
+  const int srow = st / TPR, l16 = st % TPR;
   const int nv = din / XV;                        // pieces per row
-  constexpr int NPC = (32 * S1 / XV + 15) / 16;   // pieces per thread
-  constexpr int NR = NPC * XV;
+  constexpr int NPC = (32 * S1 / XV + TPR - 1) / TPR;   // pieces per thread
+  constexpr int NR = DO_STAGE ? NPC * XV : 1;
   const uint32_t Au = (uint32_t)tk.A;
   const uint32_t q_step = 32u * gridDim.x, b_step = q_step / Au, a_step = q_step % Au;
   const uint32_t b_last = (uint32_t)(R - 1) / Au, a_last = (uint32_t)(R - 1) % Au;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     const float* xrow = tk.x + (long)fr * din;
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
-      const int c = l16 + 16 * k;
+      const int c = l16 + TPR * k;
       const int cc = (c < nv) ? c : 0;  // a piece past the row end is loaded from the row start and stored to a dummy slot
       if (XV == 2) {
         const float2 t = reinterpret_cast<const float2*>(xrow)[cc];
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     u8* base = lds + L.xs + buf * WIMG + WROW * srow;
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
-      const int c = l16 + 16 * k;
+      const int c = l16 + TPR * k;
       const bool ok = c < nv;
       const int col = XV * c;  // first feature of the piece
       u8* qa = ok ? (base + ((16 * (col >> 3)) ^ xsw) + 2 * (col & 7)) : xs_dummy;
@@ -294,24 +303,26 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
   int r_act = 0, n_act = 0;
   float r_f0 = 0.0f, r_f1 = 0.0f, n_f0 = 0.0f, n_f1 = 0.0f;
   uint32_t r_m = 1u, n_m = 1u;
-  Cursor cs = cursor_at(srow), cl = cursor_at(lrow);
+  Cursor cs = cursor_at(DO_STAGE ? srow : 0), cl = cursor_at(DO_LOSS ? lrow : 0);
   int32_t ps_next = 0, pl_next = 0;
   uint32_t as_next = 0, al_next = 0;
   if (it < ntiles) {
-    cursor_gather(cs, ps_next, as_next);
-    stage_issue((uint32_t)ps_next * Au + as_next, xr);
-    if (loss_thread) {
+    if constexpr (DO_STAGE) {
+      cursor_gather(cs, ps_next, as_next);
+      stage_issue((uint32_t)ps_next * Au + as_next, xr);
+    }
+    if constexpr (DO_LOSS) {
       cursor_gather(cl, pl_next, al_next);
       load_row((uint32_t)pl_next * Au + al_next, r_act, r_f0, r_f1, r_m);
     }
-    stage_commit(0, xr);
-    cursor_advance(cs);
-    cursor_advance(cl);
-    if (it + gridDim.x < ntiles) {
-      cursor_gather(cs, ps_next, as_next);
-      if (loss_thread) cursor_gather(cl, pl_next, al_next);
+    if constexpr (DO_STAGE) {
+      stage_commit(0, xr);
       cursor_advance(cs);
-      cursor_advance(cl);
+    }
+    if constexpr (DO_LOSS) cursor_advance(cl);
+    if (it + gridDim.x < ntiles) {
+      if constexpr (DO_STAGE) { cursor_gather(cs, ps_next, as_next); cursor_advance(cs); }
+      if constexpr (DO_LOSS) { cursor_gather(cl, pl_next, al_next); cursor_advance(cl); }
     }
   }
   __syncthreads();
@@ -347,8 +358,9 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     const bool have_next = itn < ntiles;
     const u8* const XSI = lds + L.xs + buf * WIMG;
     // rows of the next tile from the indices loaded a tile ago
-    uint32_t xrow_next = (uint32_t)ps_next * Au + as_next, lrow_next = (uint32_t)pl_next * Au + al_next;
-    asm volatile("" : "+v"(xrow_next), "+v"(lrow_next));
+    uint32_t xrow_next = DO_STAGE ? ((uint32_t)ps_next * Au + as_next) : 0u, lrow_next = DO_LOSS ? ((uint32_t)pl_next * Au + al_next) : 0u;
+    if constexpr (DO_STAGE) asm volatile("" : "+v"(xrow_next));
+    if constexpr (DO_LOSS) asm volatile("" : "+v"(lrow_next));
 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
@@ -384,13 +396,11 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     WSTAMP(1);
     // next tile's gathers: their latency hides under P2 .. P3
     if (have_next) {
-      stage_issue(xrow_next, xr);
-      if (loss_thread) load_row(lrow_next, n_act, n_f0, n_f1, n_m);
+      if constexpr (DO_STAGE) stage_issue(xrow_next, xr);
+      if constexpr (DO_LOSS) load_row(lrow_next, n_act, n_f0, n_f1, n_m);
       if (itn + gridDim.x < ntiles) {
-        cursor_gather(cs, ps_next, as_next);
-        if (loss_thread) cursor_gather(cl, pl_next, al_next);
-        cursor_advance(cs);
-        cursor_advance(cl);
+        if constexpr (DO_STAGE) { cursor_gather(cs, ps_next, as_next); cursor_advance(cs); }
+        if constexpr (DO_LOSS) { cursor_gather(cl, pl_next, al_next); cursor_advance(cl); }
       }
     }
     WSTAMP(2);
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     WSTAMP(6);
 
     // ---------------------------------------------------------------- P3: loss, d loss / d logits (x R) -> dy image
-    if (loss_thread) {
+    if constexpr (DO_LOSS) {
       const float lo_c = 1.0f - tk.clip_eps, hi_c = 1.0f + tk.clip_eps;
       const bool rvalid = (it * 32 + lrow) < R;
       const float* yp = YP + lrow * YSTR + lo;
@@ -493,7 +503,9 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     }
     // the next tile's x rows have arrived: split + store them into the other buffer (its last readers, the dW1 product of
     // the previous tile, finished before barrier A; it is read again from the next tile's P1 on, three barriers away)
-    if (have_next) stage_commit(buf ^ 1, xr);
+    if constexpr (DO_STAGE) {
+      if (have_next) stage_commit(buf ^ 1, xr);
+    }
     WSTAMP(7);
     __syncthreads();  // B2: dy of all 32 rows visible; every reader of the partial logits is done
     WSTAMP(8);
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
     if (o < no) slab[oW3 + (16 * v + i) * no + o] = gW3[r] * invR;
   }
   float* red = reinterpret_cast<float*>(lds + L.h1);  // epilogue scratch (the tile loop is over)
-  if (loss_thread) {
+  if constexpr (DO_LOSS) {
     float x = ab3;
 #pragma unroll
     for (int m = NO; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
@@ -651,6 +663,20 @@ __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8La
 #ifndef MAVA_W8_W2RES
 #define MAVA_W8_W2RES false
 #endif
+template <int NO, int S1, int XV, bool W2RES>
+__global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8Layout L) {
+  extern __shared__ __attribute__((aligned(16))) u8 lds[];
+  if constexpr (NO == 8) {
+    if (threadIdx.x < 256) {
+      w8_body<NO, S1, XV, W2RES, 1>(tk, L, lds);
+    } else {
+      w8_body<NO, S1, XV, W2RES, 2>(tk, L, lds);
+    }
+  } else {
+    w8_body<NO, S1, XV, W2RES, 0>(tk, L, lds);
+  }
+}
+
 template <int NO, int S1, int XV>
 int launch_w8(const TrainTask& tk, int n_slab, hipStream_t s) {
   const W8Layout L = make_w8_layout();

@@ -197,16 +197,22 @@ template <int STEPS>
 __device__ __forceinline__ void pack_w1_body(const float* __restrict__ P, int din, uint4* __restrict__ out, int tid, float scale) {
   const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   float v[STEPS][8];
+  // pass 1: nothing but loads (rows past din clamped to a valid address); pass 2: select, scale, split.  A select or a
+  // multiplication next to its load made the compiler wait for every load in turn - 144 round trips: 62 instead of 9 us
+  // for the stand-alone launch, 58 instead of 25 us for the Adam launch that carries this body in its last block.
 #pragma unroll
   for (int i = 0; i < STEPS; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 16 * i + 8 * h + e;
-      v[i][e] = (k <= din) ? P[k * MLP_H + 32 * w + r] * scale : 0.0f;
+      v[i][e] = P[(k <= din ? k : din) * MLP_H + 32 * w + r];
     }
+  __builtin_amdgcn_sched_barrier(0);
   float carry = 0.0f;
 #pragma unroll
   for (int i = 0; i < STEPS; ++i) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = (16 * i + 8 * h + e <= din) ? v[i][e] * scale : 0.0f;
     const Frag f = split8_carry(v[i], carry);
     const int gid = i * 256 + tid;
     out[2 * gid] = __builtin_bit_cast(uint4, f.hi);

@@ -235,8 +235,8 @@ def _load_traffic(names):
     return {}, None
 
 
-FF_TRAFFIC = ("r03_pmc_traffic.json", "r02_v5_pmc_traffic.json", "r02_v4_pmc_traffic.json", "r02_v3_pmc_traffic.json")
-REC_TRAFFIC = ("r03_rec_pmc_traffic.json", "r02_rec3_pmc_traffic.json", "r02_rec2_pmc_traffic.json", "r02_rec_pmc_traffic.json")
+FF_TRAFFIC = ("r03_v3_pmc_traffic.json", "r03_v2_pmc_traffic.json", "r03_v1_pmc_traffic.json", "r02_v5_pmc_traffic.json")
+REC_TRAFFIC = ("r03_rec2_pmc_traffic.json", "r03_rec_pmc_traffic.json", "r02_rec3_pmc_traffic.json", "r02_rec2_pmc_traffic.json")
 
 
 def ff_rooflines(L, matmul: str, timers: dict, timer_steps: int, default_shape: bool, aggregated_off: bool, continuous: bool, dev,
@@ -269,10 +269,22 @@ def ff_rooflines(L, matmul: str, timers: dict, timer_steps: int, default_shape: 
     h2_c = matmul == "f16x2" and L.Oc <= 287
     peak_a = F16X2_PEAK_TFLOPS if h2_a else F32_MFMA_PEAK_TFLOPS
     peak_c = F16X2_PEAK_TFLOPS if h2_c else F32_MFMA_PEAK_TFLOPS
-    kname = lambda h2, net: (f"ppo_train_h2_kernel<{net}> (fused fwd+loss+bwd+dW, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
-                             if h2 else f"ppo_train_kernel<{net}> (fused fwd+loss+bwd+dW, exact-f32 MFMA)")
-    tkey = lambda h2, net: next((k for k in traffic if k.startswith("ppo_train_h2_kernel" if h2 else "ppo_train_kernel")
-                                 and (("true" in k.split(",")[2]) == (net == "actor") if h2 else net in k)), None)
+    # the discrete actor up to 127 inputs / 16 actions runs on the eight-wave kernel (ppo_train_w8.hip) unless the handle's
+    # MAVA_CTX_TRAIN_VARIANT is 1
+    w8_a = h2_a and L.Oa + 1 <= 128 and L.nA <= 16 and L.ctx.get(L.ctx.TRAIN_VARIANT) == 0
+
+    def kname(h2, net):
+        if net == "actor" and w8_a:
+            return "ppo_train_w8_kernel<actor> (fused fwd+loss+bwd+dW, eight waves, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
+        if h2:
+            return f"ppo_train_h2_kernel<{net}> (fused fwd+loss+bwd+dW, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
+        return f"ppo_train_kernel<{net}> (fused fwd+loss+bwd+dW, exact-f32 MFMA)"
+
+    def tkey(h2, net):
+        if net == "actor" and w8_a:
+            return next((k for k in traffic if k.startswith("ppo_train_w8_kernel")), None)
+        return next((k for k in traffic if k.startswith("ppo_train_h2_kernel" if h2 else "ppo_train_kernel")
+                     and (("true" in k.split(",")[2]) == (net == "actor") if h2 else net in k)), None)
     roof_c = {"kernel": kname(h2_c, "critic") + (", agents of a row aggregated" if aggregated else ""),
               "bound": "mfma", "achieved": tf_c, "peak": peak_c, "unit": "TFLOP/s", "frac": tf_c / peak_c,
               "traffic": traffic.get(tkey(h2_c, "critic"), {}).get("hbm_bytes_corrected"),

@@ -121,7 +121,9 @@ int mava_mlp_param_count(int din, int n_out);
 int mava_mlp_forward_f32(const mava_ctx* ctx, const float* params, int din, int n_out, const float* x, int x_share,
                          int rows, float* out, mava_stream_t s);
 
-/* One acting step, mava/systems/ppo/ff_mappo.py:80-85: actor forward + action mask
+/* (Every *_continuous entry point and mava_rec_step_packed_f32 take ContinuousActionHead.min_scale - mava/networks.py:134,162,
+ * default 1e-3: scale = softplus(log_std) + min_scale - right after the action dimension.)
+ * One acting step, mava/systems/ppo/ff_mappo.py:80-85: actor forward + action mask
  * (networks.py:116-120) + Categorical sample / log_prob (distributions.py:146-165), and critic
  * forward, in one launch.  rows = envs*agents.  agents_view (rows, actor_din);
  * action_mask (rows, n_actions) u8 or NULL; critic_input (critic_rows/critic_share.., critic_din)
@@ -180,14 +182,14 @@ int mava_ppo_actor_grad_f32(mava_ctx* ctx, const float* params, int din, int n_a
  * mava_ppo_actor_grad_continuous_f32: _actor_loss_fn ff_mappo.py:150-180 for this head; the entropy sample of
  * ff_mappo.py:176-177 is drawn from Philox(counter (row_offset + trajectory row, ent_step, dim/2), key seed).
  * slab row = [MLP gradient | d/d log_std | actor_loss, entropy]. */
-int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int action_dim,
+int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int action_dim, float min_scale,
                                     const float* agents_view, const float* critic_params, int critic_din,
                                     const float* critic_input, int critic_share, int critic_rows,
                                     int value_broadcast, int rows, uint64_t seed, uint32_t step,
                                     const uint32_t* step_base, uint32_t row_offset, int greedy,
                                     const float* forced_action, float* action, float* log_prob, float* value,
                                     float* mean, mava_stream_t s);
-int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim, const float* agents_view,
+int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim, float min_scale, const float* agents_view,
                                        const float* action, const float* old_log_prob, const float* advantages,
                                        const double* adv_stats, const int32_t* idx, long idx_base, int Rb, int A,
                                        float clip_eps, float ent_coef, uint64_t seed, uint32_t ent_step,
@@ -306,7 +308,7 @@ int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_actions, const in
  * ContinuousActionHead(independent_std=False) (networks.py:140,161): log_std_rows is the T32 (T*Rm x action_dim) output
  * of the log_std layer (log_std may then be NULL) and dlog_std_rows receives its gradient (times grad_scale) instead of
  * dscale_partials; both NULL for the observation-independent scale. */
-int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
+int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, float min_scale, const int32_t* idx,
                                        const float* mean, const float* log_std, const float* log_std_rows,
                                        const float* action, const float* old_log_prob, const float* advantages,
                                        const double* adv_stats, int n_stats, float clip_eps, float ent_coef, uint64_t seed,
@@ -314,7 +316,7 @@ int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_d
                                        float* dlog_std_rows, float* loss_partials, float* dscale_partials, int n_blocks,
                                        mava_stream_t s);
 /* rollout epilogue: T32 means of one step -> action (rows, action_dim) = tanh(loc + scale * noise), log_prob (rows) */
-int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std,
+int mava_seq_sample_continuous_f32(int rows, int action_dim, float min_scale, const float* mean, const float* log_std,
                                    const float* log_std_rows, uint64_t seed,
                                    uint32_t step, uint32_t row_offset, int greedy, float* action, float* log_prob,
                                    mava_stream_t s);
@@ -361,7 +363,7 @@ int mava_rec_step_f32(const float* actor_params, int actor_din, int n_actions, c
                       float* value, mava_stream_t s);
 /* the same fused acting step with ContinuousActionHead: actor_params = [recurrent network | log_std(action_dim)],
  * action (rows_a, action_dim) float = tanh(loc + scale * noise) (noise stream of mava_seq_sample_continuous_f32). */
-int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim, const float* agents_view,
+int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim, float min_scale, const float* agents_view,
                                  const uint8_t* done_a, const float* h_actor_in, float* h_actor_out, int rows_a,
                                  uint64_t seed, uint32_t step, uint32_t row_offset, int greedy, float* action,
                                  float* log_prob, const float* critic_params, int critic_din,
@@ -378,7 +380,7 @@ int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int a
 long mava_rec_step_pack_bytes(int din);
 int mava_rec_step_pack_f32(const float* params, int din, void* pack, mava_stream_t s);
 int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float* actor_params, int actor_din,
-                             int n_actions, const float* agents_view, const uint8_t* action_mask, const uint8_t* done_a,
+                             int n_actions, float min_scale, const float* agents_view, const uint8_t* action_mask, const uint8_t* done_a,
                              const float* h_actor_in, float* h_actor_out, int rows_a, uint64_t seed, uint32_t step,
                              uint32_t row_offset, int greedy, int32_t* action, float* action_f, float* log_prob,
                              const float* critic_params, int critic_din, const float* critic_input, int critic_share,

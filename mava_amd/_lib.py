@@ -50,13 +50,10 @@ _SIGNATURES = {
     "mava_mlp_forward_f32": [vp, vp, i32, i32, vp, i32, i32, vp, vp],
     "mava_policy_step_f32": [vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
                              vp, vp, vp, vp, vp, vp],
-    "mava_policy_step_continuous_f32": [vp, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32,
-                                        vp, vp, vp, vp, vp, vp],
-    "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32,
-                                           u32, vp, lng, i32, vp],
-    "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32,
-                                           u32, f32, vp, vp, vp, vp, i32, vp],
-    "mava_seq_sample_continuous_f32": [i32, i32, vp, vp, vp, u64, u32, u32, i32, vp, vp, vp],
+    "mava_policy_step_continuous_f32": [vp, vp, i32, i32, f32, vp, vp, i32, vp, i32, i32, i32, i32, u64, u32, vp, u32, i32, vp, vp, vp, vp, vp, vp],
+    "mava_ppo_actor_grad_continuous_f32": [vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, lng, i32, i32, f32, f32, u64, u32, u32, vp, lng, i32, vp],
+    "mava_seq_actor_loss_continuous_f32": [i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, u64, u32, u32, f32, vp, vp, vp, vp, i32, vp],
+    "mava_seq_sample_continuous_f32": [i32, i32, f32, vp, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_adv_stats_blocks": [],
     "mava_adv_stats_f64": [vp, vp, lng, i32, i32, vp, vp],
     "mava_adv_stats_batched_f64": [vp, vp, lng, i32, i32, i32, vp, vp],
@@ -71,8 +68,7 @@ _SIGNATURES = {
     "mava_gru_scan_fwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "mava_gru_scan_bwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, i32, vp],
-    "mava_rec_step_continuous_f32": [vp, i32, i32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32,
-                                     vp, vp, i32, i32, vp, vp],
+    "mava_rec_step_continuous_f32": [vp, i32, i32, f32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp],
     "mava_rec_step_f32": [vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp,
                           i32, i32, vp, vp],
     "mava_seq_critic_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, i32, vp],
@@ -90,8 +86,7 @@ _SIGNATURES = {
     "mava_broadcast_f32": [vp, vp, C.c_size_t, i32, vp],
     "mava_comm_destroy": [vp],
     "mava_rec_step_pack_f32": [vp, i32, vp, vp],
-    "mava_rec_step_packed_f32": [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, vp, i32, vp, i32, vp,
-                                 i32, vp, vp, i32, i32, vp, vp],
+    "mava_rec_step_packed_f32": [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp],
     "mava_seq_sample_f32": [i32, i32, vp, vp, u64, u32, u32, i32, vp, vp, vp],
     "mava_t32_convert_f32": [vp, i32, i32, i32, vp, vp],
 }

@@ -77,6 +77,7 @@ struct StepOut {
   float* action_f;               // (R, no) sampled actions in (-1, 1)
   const float* log_std;          // (no) raw scale parameters
   const float* forced_action_f;  // optional (R, no): score these actions instead of sampling
+  float min_scale;               // scale = softplus(log_std) + min_scale (networks.py:134,162)
 };
 
 // Per-wave actor: block `bid` of the `nblk` actor blocks; each wave carries whole 32-row tiles through the three
@@ -102,7 +103,7 @@ __device__ __forceinline__ void actor_step_body(const FwdTask& actor, float* lds
 #pragma unroll
       for (int o = 0; o < NOA; ++o) {
         if (o < no) {
-          const float sc = tn::scale_of(out.log_std[o]);
+          const float sc = tn::scale_of(out.log_std[o], out.min_scale);
           float a;
           if (out.forced_action_f != nullptr) {
             a = valid ? out.forced_action_f[(long)row * no + o] : 0.0f;
@@ -326,7 +327,7 @@ static int policy_step_impl(int variant, const float* actor_params, int actor_di
                             int value_broadcast, int rows, uint64_t seed, uint32_t step, const uint32_t* step_base,
                             uint32_t row_offset, int greedy, const int32_t* forced_action,
                             int32_t* action, float* log_prob, float* value, float* logits,
-                            float* action_f, const float* forced_action_f, hipStream_t s) {
+                            float* action_f, const float* forced_action_f, float min_scale, hipStream_t s) {
   MAVA_ARG_CHECK(actor_din >= 1 && critic_din >= 1 && n_actions >= 1 && n_actions <= 32, 0,
                  "mava_policy_step_f32: actor_din=%d critic_din=%d n_actions=%d unsupported",
                  actor_din, critic_din, n_actions);
@@ -350,7 +351,7 @@ static int policy_step_impl(int variant, const float* actor_params, int actor_di
   FwdTask ta = {actor_params, agents_view, actor_din, n_actions, 1, pick_xv(agents_view, actor_din), rows};
   const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
   StepOut so = {action, log_prob, value, logits, forced_action, step_base, action_f,
-                actor_params ? actor_params + mlp_param_count(actor_din, n_actions) : nullptr, forced_action_f};
+                actor_params ? actor_params + mlp_param_count(actor_din, n_actions) : nullptr, forced_action_f, min_scale};
   // Few critic tiles (at most one per CU next to the actor's blocks): hybrid launch, cooperative critic blocks
   {
     const int tiles_c = mava_cdiv(critic_rows, 32);
@@ -402,10 +403,11 @@ extern "C" int mava_policy_step_f32(const mava_ctx* ctx, const float* actor_para
                                     hipStream_t s) {
   return policy_step_impl(mava_ctx_policy_variant(ctx), actor_params, actor_din, n_actions, agents_view, action_mask, critic_params, critic_din,
                           critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
-                          row_offset, greedy, forced_action, action, log_prob, value, logits, nullptr, nullptr, s);
+                          row_offset, greedy, forced_action, action, log_prob, value, logits, nullptr, nullptr, 0.0f, s);
 }
 
 extern "C" int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float* actor_params, int actor_din, int action_dim,
+                                               float min_scale,
                                                const float* agents_view, const float* critic_params, int critic_din,
                                                const float* critic_input, int critic_share, int critic_rows,
                                                int value_broadcast, int rows, uint64_t seed, uint32_t step,
@@ -415,5 +417,5 @@ extern "C" int mava_policy_step_continuous_f32(const mava_ctx* ctx, const float*
   MAVA_ARG_CHECK(rows == 0 || action != nullptr, 2, "mava_policy_step_continuous_f32: null action pointer");
   return policy_step_impl(mava_ctx_policy_variant(ctx), actor_params, actor_din, action_dim, agents_view, nullptr, critic_params, critic_din,
                           critic_input, critic_share, critic_rows, value_broadcast, rows, seed, step, step_base,
-                          row_offset, greedy, nullptr, nullptr, log_prob, value, mean, action, forced_action, s);
+                          row_offset, greedy, nullptr, nullptr, log_prob, value, mean, action, forced_action, min_scale, s);
 }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void ppo_train_kernel(TrainTask tk, TrainLd
   // continuous head: scale of this lane's action dimension, and the per-lane partial of d loss / d scale[lo]
   float als = 0.0f;
   const float ls_raw = CONT ? tk.params[mlp_param_count(tk.din, tk.no) + ((lane & (NO - 1)) < tk.no ? (lane & (NO - 1)) : 0)] : 0.0f;
-  const float sc_lo = CONT ? tn::scale_of(ls_raw) : 1.0f;
+  const float sc_lo = CONT ? tn::scale_of(ls_raw, tk.min_scale) : 1.0f;
 
 
   // per-row inputs of the loss (row j of the tile), prefetched one tile ahead
@@ -1023,7 +1023,7 @@ extern "C" int mava_ppo_actor_grad_f32(mava_ctx* ctx, const float* params, int d
 // Continuous action head (networks.py:127-169): params = [MLP(din -> 128 -> 128 -> action_dim) | log_std(action_dim)],
 // slab row = gradient in the same layout, then (actor_loss, entropy) sums.  The entropy term uses one reparameterised
 // sample per (row, dimension) from Philox(counter = (row_offset + trajectory row, ent_step, dim/2), key = seed).
-extern "C" int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim,
+extern "C" int mava_ppo_actor_grad_continuous_f32(const float* params, int din, int action_dim, float min_scale,
                                                   const float* agents_view, const float* action,
                                                   const float* old_log_prob, const float* advantages,
                                                   const double* adv_stats, const int32_t* idx, long idx_base, int Rb,
@@ -1046,6 +1046,7 @@ extern "C" int mava_ppo_actor_grad_continuous_f32(const float* params, int din, 
   tk.stats = adv_stats; tk.clip_eps = clip_eps; tk.ent_coef = ent_coef; tk.slab = slab;
   tk.slab_stride = slab_stride;
   tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32); tk.ent_step = ent_step; tk.row_offset = row_offset;
+  tk.min_scale = min_scale;
   tk.stamps = g_stamps;
   if (action_dim <= 8) return dispatch_kt<8, true, true>(tk, n_slab, s);
   return dispatch_kt<16, true, true>(tk, n_slab, s);

@@ -19,6 +19,7 @@ struct TrainTask {
   const int32_t* action;   // (TE*A)
   const float* action_f;   // continuous head: (TE*A, no) actions in (-1, 1); the raw scales follow the MLP in params
   uint32_t seed_lo, seed_hi, ent_step, row_offset;  // continuous head: Philox key / counters of the entropy sample
+  float min_scale;         // continuous head: scale = softplus(log_std) + min_scale
   const float* old_logp;   // (TE*A)
   const float* adv;        // (TE*A)
   const double* stats;     // STATS_BLOCKS x {sum, sumsq} partials of the minibatch advantages

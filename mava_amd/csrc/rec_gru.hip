@@ -262,6 +262,7 @@ struct SeqLossTask {
   float* logp_out;
   float* value_out;
   // continuous head (tanh_normal.h): y holds the means
+  float min_scale;           // scale = softplus(raw) + min_scale (networks.py:134,162)
   const float* log_std;      // (no) raw scales
   const float* log_std_rows; // T32 (rows x no) raw scales per row (ContinuousActionHead(independent_std=False)) or null
   float* dlog_std_rows;      // T32: d loss / d raw scale per row (times grad_scale), with log_std_rows
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
   float sc[NO], ds[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
-    sc[o] = tk.log_std != nullptr ? tn::scale_of(tk.log_std[o < tk.no ? o : 0]) : 1.0f;
+    sc[o] = tk.log_std != nullptr ? tn::scale_of(tk.log_std[o < tk.no ? o : 0], tk.min_scale) : 1.0f;
     ds[o] = 0.0f;
   }
   float la = 0.0f, lb = 0.0f;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void seq_loss_cont_kernel(SeqLossTask tk) {
         const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
         if (tk.log_std_rows != nullptr) {  // state-dependent scale: networks.py:140,161
           lsr[o] = tk.log_std_rows[(tile * tk.no + o) * 32 + jj];
-          sc[o] = tn::scale_of(lsr[o]);
+          sc[o] = tn::scale_of(lsr[o], tk.min_scale);
         }
         const tn::LogProb l = tn::log_prob(tk.action_f[er * tk.no + o], mean, sc[o]);
         lp += l.lp;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256) void seq_sample_cont_kernel(SeqLossTask tk) {
   for (int o = 0; o < NO; ++o) {
     if (o < tk.no) {
       const float mean = tk.y[(tile * tk.no + o) * 32 + jj];
-      const float sc = tn::scale_of(tk.log_std_rows != nullptr ? tk.log_std_rows[(tile * tk.no + o) * 32 + jj] : tk.log_std[o]);
+      const float sc = tn::scale_of(tk.log_std_rows != nullptr ? tk.log_std_rows[(tile * tk.no + o) * 32 + jj] : tk.log_std[o], tk.min_scale);
       const float eps = tk.greedy ? 0.0f : tn::noise(gid, tk.step, o, tn::STREAM_SAMPLE, tk.seed_lo, tk.seed_hi);
       const float a = tanhf(fmaf(sc, eps, mean));
       lp += tn::log_prob(a, mean, sc).lp;
@@ -605,7 +606,7 @@ extern "C" int mava_seq_actor_loss_f32(int T, int Rm, int E, int A, int n_action
   return MAVA_OK;
 }
 
-extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, const int32_t* idx,
+extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, int action_dim, float min_scale, const int32_t* idx,
                                                   const float* mean, const float* log_std, const float* log_std_rows,
                                                   const float* action,
                                                   const float* old_log_prob, const float* advantages,
@@ -622,6 +623,7 @@ extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, i
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.no = action_dim; tk.idx = idx; tk.y = mean; tk.dy = dmean;
   MAVA_ARG_CHECK((log_std_rows == nullptr) == (dlog_std_rows == nullptr), 2,
                  "mava_seq_actor_loss_continuous_f32: log_std_rows and dlog_std_rows come together");
+  tk.min_scale = min_scale;
   tk.log_std = log_std; tk.log_std_rows = log_std_rows; tk.dlog_std_rows = dlog_std_rows; tk.action_f = action; tk.f0 = old_log_prob; tk.f1 = advantages; tk.stats = adv_stats;
   tk.n_stats = n_stats; tk.clip_eps = clip_eps; tk.coef = ent_coef; tk.loss_partials = loss_partials;
   tk.dscale_partials = dscale_partials; tk.seed_lo = (uint32_t)seed; tk.seed_hi = (uint32_t)(seed >> 32);
@@ -632,14 +634,14 @@ extern "C" int mava_seq_actor_loss_continuous_f32(int T, int Rm, int E, int A, i
   return MAVA_OK;
 }
 
-extern "C" int mava_seq_sample_continuous_f32(int rows, int action_dim, const float* mean, const float* log_std,
+extern "C" int mava_seq_sample_continuous_f32(int rows, int action_dim, float min_scale, const float* mean, const float* log_std,
                                               const float* log_std_rows, uint64_t seed, uint32_t step, uint32_t row_offset, int greedy,
                                               float* action, float* log_prob, hipStream_t s) {
   MAVA_ARG_CHECK(rows >= 1 && rows % 32 == 0 && action_dim >= 1 && action_dim <= 16, 0,
                  "mava_seq_sample_continuous_f32: rows=%d action_dim=%d", rows, action_dim);
   MAVA_ARG_CHECK(mean && (log_std || log_std_rows) && action && log_prob, 1, "mava_seq_sample_continuous_f32: null pointer argument");
   SeqLossTask tk = {};
-  tk.Rm = rows; tk.no = action_dim; tk.y = mean; tk.log_std = log_std; tk.log_std_rows = log_std_rows; tk.seed_lo = (uint32_t)seed;
+  tk.Rm = rows; tk.no = action_dim; tk.min_scale = min_scale; tk.y = mean; tk.log_std = log_std; tk.log_std_rows = log_std_rows; tk.seed_lo = (uint32_t)seed;
   tk.seed_hi = (uint32_t)(seed >> 32); tk.step = step; tk.row_offset = row_offset; tk.greedy = greedy;
   tk.action_f_out = action; tk.logp_out = log_prob;
   const int blocks = mava_cdiv(rows, 256);

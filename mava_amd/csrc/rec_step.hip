@@ -209,7 +209,7 @@ __device__ __forceinline__ void rec_step_body(const RecNet& nt, const RecStepOut
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
           if (o < no) {
-            const float sc = tn::scale_of(log_std[o]);
+            const float sc = tn::scale_of(log_std[o], out.min_scale);
             const float eps = out.greedy ? 0.0f : tn::noise(gid, out.step, o, tn::STREAM_SAMPLE, out.seed_lo, out.seed_hi);
             const float a = tanhf(fmaf(sc, eps, y[o]));
             lp += tn::log_prob(a, y[o], sc).lp;
@@ -287,7 +287,7 @@ static int rec_step_impl(const float* actor_params, int actor_din, int n_actions
                          int greedy, int32_t* action, float* action_f, float* log_prob, const float* critic_params,
                          int critic_din, const float* critic_input, int critic_share, const uint8_t* done_c,
                          int done_c_stride, const float* h_critic_in, float* h_critic_out, int rows_c, int value_broadcast,
-                         float* value, hipStream_t s, const void* pack_a = nullptr, const void* pack_c = nullptr) {
+                         float* value, hipStream_t s, float min_scale = 0.0f, const void* pack_a = nullptr, const void* pack_c = nullptr) {
   MAVA_ARG_CHECK(rows_a >= 0 && rows_c >= 0 && rows_a % 32 == 0 && rows_c % 32 == 0, 0,
                  "mava_rec_step_f32: rows must be multiples of 32 (rows_a=%d rows_c=%d)", rows_a, rows_c);
   if (rows_a == 0 && rows_c == 0) return MAVA_OK;
@@ -315,6 +315,7 @@ static int rec_step_impl(const float* actor_params, int actor_din, int n_actions
   so.row_offset = row_offset; so.greedy = greedy; so.action = action; so.log_prob = log_prob; so.value = value;
   so.vbroadcast = value_broadcast;
   so.action_f = action_f;
+  so.min_scale = min_scale;
   if (pack_a != nullptr && pack_c != nullptr && rows_a > 0 && rows_c > 0) {  // split-f16 operands, pre-packed weights
     const int rc = mava_rec_step_h2_launch(a, c, pack_a, pack_c, so, s);
     if (rc <= 0) return rc;
@@ -360,7 +361,7 @@ extern "C" int mava_rec_step_f32(const float* actor_params, int actor_din, int n
                        critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s);
 }
 
-extern "C" int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim,
+extern "C" int mava_rec_step_continuous_f32(const float* actor_params, int actor_din, int action_dim, float min_scale,
                                             const float* agents_view, const uint8_t* done_a, const float* h_actor_in,
                                             float* h_actor_out, int rows_a, uint64_t seed, uint32_t step,
                                             uint32_t row_offset, int greedy, float* action, float* log_prob,
@@ -372,14 +373,14 @@ extern "C" int mava_rec_step_continuous_f32(const float* actor_params, int actor
                  "mava_rec_step_continuous_f32: action_dim <= 16 and a non-null action buffer are required");
   return rec_step_impl(actor_params, actor_din, action_dim, agents_view, nullptr, done_a, h_actor_in, h_actor_out, rows_a,
                        seed, step, row_offset, greedy, nullptr, action, log_prob, critic_params, critic_din, critic_input,
-                       critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s);
+                       critic_share, done_c, done_c_stride, h_critic_in, h_critic_out, rows_c, value_broadcast, value, s, min_scale);
 }
 
 // The same acting step on split-f16 operands (rec_step_h2.hip): pack_a / pack_c are the two networks' weights as written
 // by mava_rec_step_pack_f32 from the CURRENT parameters (mava_rec_step_pack_bytes(din) bytes each; re-pack after every
 // parameter update).  Shapes the f16x2 kernel does not instantiate (more than 16 outputs) run the exact-f32 kernel.
 extern "C" int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, const float* actor_params, int actor_din,
-                                        int n_actions, const float* agents_view, const uint8_t* action_mask,
+                                        int n_actions, float min_scale, const float* agents_view, const uint8_t* action_mask,
                                         const uint8_t* done_a, const float* h_actor_in, float* h_actor_out, int rows_a,
                                         uint64_t seed, uint32_t step, uint32_t row_offset, int greedy, int32_t* action,
                                         float* action_f, float* log_prob, const float* critic_params, int critic_din,
@@ -391,5 +392,5 @@ extern "C" int mava_rec_step_packed_f32(const void* pack_a, const void* pack_c, 
   return rec_step_impl(actor_params, actor_din, n_actions, agents_view, action_f ? nullptr : action_mask, done_a, h_actor_in,
                        h_actor_out, rows_a, seed, step, row_offset, greedy, action_f ? nullptr : action, action_f, log_prob,
                        critic_params, critic_din, critic_input, critic_share, done_c, done_c_stride, h_critic_in, h_critic_out,
-                       rows_c, value_broadcast, value, s, pack_a, pack_c);
+                       rows_c, value_broadcast, value, s, min_scale, pack_a, pack_c);
 }

@@ -465,7 +465,7 @@ __device__ __forceinline__ void rec_step_h2_body(const NetH2& nh, const RecStepO
       for (int k = 0; k < OPL; ++k) {
         const int o = l8 + 8 * k;
         if (o < no) {
-          const float sc = tn::scale_of(log_std[o]);
+          const float sc = tn::scale_of(log_std[o], out.min_scale);
           const float eps = out.greedy ? 0.0f : tn::noise(gid, out.step, o, tn::STREAM_SAMPLE, out.seed_lo, out.seed_hi);
           const float a = tanhf(fmaf(sc, eps, y[k]));
           lp += tn::log_prob(a, y[k], sc).lp;

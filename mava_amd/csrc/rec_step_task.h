@@ -24,6 +24,7 @@ struct RecStepOut {
   float* value;          // (rows_c * vbroadcast)
   int vbroadcast;
   float* action_f;       // continuous head (tanh_normal.h) when not null: (rows, no) actions; log_std follows bhead
+  float min_scale;       // continuous head: scale = softplus(log_std) + min_scale
 };
 
 

@@ -14,7 +14,7 @@ namespace tn {
 constexpr float THRESH = 0.999f;
 constexpr float ATANH_THRESH = 3.8002011672502f;   // atanh(0.999)
 constexpr float LOG_EPS = -6.907755278982136f;     // log(1 - 0.999)
-constexpr float MIN_SCALE = 1e-3f;                 // ContinuousActionHead.min_scale
+constexpr float MIN_SCALE = 1e-3f;                 // ContinuousActionHead.min_scale default (networks.py:134); passed per call
 constexpr float HALF_LOG_2PI = 0.9189385332046727f;
 constexpr float LOG2 = 0.6931471805599453f;
 constexpr float RSQRT2 = 0.7071067811865476f;
@@ -23,7 +23,7 @@ constexpr uint32_t STREAM_ENTROPY = 0x544e454eu;  // "TNEN": entropy sample of t
 
 __device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float scale_of(float raw) { return softplus(raw) + MIN_SCALE; }
+__device__ __forceinline__ float scale_of(float raw, float min_scale) { return softplus(raw) + min_scale; }
 
 // log of the standard normal CDF
 __device__ __forceinline__ float log_ndtr(float z) {

@@ -47,9 +47,9 @@ class TanhNormal:
 
     THRESH = 0.999
 
-    def __init__(self, loc: torch.Tensor, log_std: torch.Tensor):
+    def __init__(self, loc: torch.Tensor, log_std: torch.Tensor, min_scale: float = 1e-3):
         self.loc = loc
-        self.scale = torch.nn.functional.softplus(log_std) + 1e-3
+        self.scale = torch.nn.functional.softplus(log_std) + float(min_scale)
 
     def mode(self) -> torch.Tensor:
         return torch.tanh(self.loc)  # distributions.py:75-77

@@ -447,7 +447,7 @@ class GenericActor(_GenericFF):
         outs = self._apply_rows(flat, av.reshape(-1, self.din))
         if self.continuous:
             ls = self.log_std(flat.float()) if self.independent_std else outs[1].view(*lead, self.n_out)
-            return TanhNormal(outs[0].view(*lead, self.n_out), ls)
+            return TanhNormal(outs[0].view(*lead, self.n_out), ls, self.action_head.min_scale)
         mask = observation.action_mask
         return Categorical(outs[0].view(*lead, self.n_out), None if mask is None else mask.reshape(*lead, self.n_out))
 

@@ -102,6 +102,7 @@ class FFLearner:
         # ff_mappo.py:348-350: the action head of the configuration, sized by the env's action dimension
         action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
         self.continuous = type(action_head).__name__ == "ContinuousActionHead"
+        self.min_scale = float(getattr(action_head, "min_scale", 1e-3))
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
             self.reps.append(_Replica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
@@ -377,7 +378,7 @@ class FFLearner:
                 if self.generic:
                     self._timed("policy_step", self._generic_act, u, rep, t, step)
                 elif self.continuous:
-                    self._timed("policy_step", ops.policy_step_continuous, pa, pc, av, cx, action_dim=self.nA,
+                    self._timed("policy_step", ops.policy_step_continuous, pa, pc, av, cx, action_dim=self.nA, min_scale=self.min_scale,
                                 out=(rep.action[t].view(EA, self.nA), rep.log_prob[t].view(EA), rep.value[t].view(EA)),
                                 **common)
                 else:
@@ -432,7 +433,7 @@ class FFLearner:
                 self._timed("actor_grad", ops.ppo_actor_grad_continuous, pa, av, rep.action.view(TEA, self.nA),
                             rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base, self.Rb, A, self.nA,
                             float(s.clip_eps), float(s.ent_coef), self.seed, self.ent_step,
-                            (self.rank * self.U + u) * TEA, self.slab_a)
+                            (self.rank * self.U + u) * TEA, self.slab_a, min_scale=self.min_scale)
             else:
                 self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
                             rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base,
@@ -492,7 +493,7 @@ class FFLearner:
         gstep = (self.t_global + step) & 0xFFFFFFFF  # (the general path is not graph-captured: host-side step counter)
         if self.continuous:
             ind = an.independent_std
-            ops.check(L.mava_seq_sample_continuous_f32(EA, self.nA, ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
+            ops.check(L.mava_seq_sample_continuous_f32(EA, self.nA, self.min_scale, ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
                                                        None if ind else ops.ptr(outs[1]), seed, gstep, row_off, 0, ops.ptr(rep.action[t]),
                                                        ops.ptr(rep.log_prob[t]), st), "mava_seq_sample_continuous_f32")
         else:
@@ -523,7 +524,7 @@ class FFLearner:
             if self.continuous:
                 ind = an.independent_std
                 ops.check(L.mava_seq_actor_loss_continuous_f32(
-                    1, Rm, TE, A, self.nA, ops.ptr(idx), ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
+                    1, Rm, TE, A, self.nA, self.min_scale, ops.ptr(idx), ops.ptr(outs[0]), ops.ptr(an.log_std(pa)) if ind else None,
                     None if ind else ops.ptr(outs[1]), ops.ptr(rep.action), ops.ptr(rep.log_prob), ops.ptr(rep.adv), ops.ptr(self.stats),
                     self.stats.shape[0], float(s.clip_eps), float(s.ent_coef), self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF,
                     ((self.rank * self.U + u) * TE * A) & 0xFFFFFFFF, gs, ops.ptr(wa.dout[0]), None if ind else ops.ptr(wa.dout[1]),

@@ -55,8 +55,9 @@ class ContinuousActionHead:
     def __init__(self, action_dim: int, min_scale: float = 1e-3, independent_std: bool = True, **_: Any):
         self.action_dim = int(action_dim)
         self.independent_std = bool(independent_std)
-        if abs(float(min_scale) - 1e-3) > 1e-12:
-            raise NotImplementedError(f"mava_amd's kernels implement ContinuousActionHead(min_scale=1e-3) (the reference's default); got {min_scale}")
+        self.min_scale = float(min_scale)  # scale = softplus(log_std) + min_scale (mava/networks.py:134,162); a kernel argument
+        if not (self.min_scale >= 0.0):
+            raise ValueError(f"ContinuousActionHead.min_scale must be >= 0, got {min_scale}")
         if self.action_dim > 16:
             raise NotImplementedError(f"continuous action heads are instantiated up to 16 dimensions, got {self.action_dim}")
 
@@ -213,7 +214,7 @@ class FeedForwardActor(_FeedForwardNet):
         flat = flat.contiguous()
         logits = ops.mlp_forward(flat[: self.num_mlp_params], self.din, self.n_out, x)
         if self.continuous:
-            return TanhNormal(logits.view(*lead, self.n_out), self._log_std(flat))
+            return TanhNormal(logits.view(*lead, self.n_out), self._log_std(flat), self.action_head.min_scale)
         mask = observation.action_mask
         return Categorical(logits.view(*lead, self.n_out), None if mask is None else mask.reshape(*lead, self.n_out))
 

@@ -235,7 +235,7 @@ def policy_step_continuous(actor_params, critic_params, agents_view, critic_inpu
                            critic_share: int = 1, critic_rows: Optional[int] = None, value_broadcast: int = 1,
                            seed: int, step: int, row_offset: int = 0, greedy: bool = False, forced_action=None,
                            out=None, want_mean: bool = False, step_base: Optional[torch.Tensor] = None,
-                           ctx: Optional[Ctx] = None):
+                           ctx: Optional[Ctx] = None, min_scale: float = 1e-3):
     """One acting step with the continuous head: returns (action f32 (rows, action_dim), log_prob (rows), value,
     mean|None)."""
     if step_base is not None:
@@ -270,7 +270,7 @@ def policy_step_continuous(actor_params, critic_params, agents_view, critic_inpu
             raise ValueError("out: wrong sizes")
     mean = torch.empty((rows, action_dim), dtype=torch.float32, device=dev) if want_mean else None
     check(
-        lib().mava_policy_step_continuous_f32(ctx_ptr(ctx), ptr(actor_params), actor_din, action_dim, ptr(agents_view),
+        lib().mava_policy_step_continuous_f32(ctx_ptr(ctx), ptr(actor_params), actor_din, action_dim, float(min_scale), ptr(agents_view),
                                               ptr(critic_params), critic_din, ptr(critic_input), critic_share,
                                               critic_rows, value_broadcast, rows, seed & 0xFFFFFFFFFFFFFFFF,
                                               step & 0xFFFFFFFF, ptr(step_base), row_offset & 0xFFFFFFFF, int(greedy),
@@ -283,7 +283,7 @@ def policy_step_continuous(actor_params, critic_params, agents_view, critic_inpu
 
 def ppo_actor_grad_continuous(params, agents_view, action, old_log_prob, advantages, stats, idx, idx_base: int,
                               Rb: int, A: int, action_dim: int, clip_eps: float, ent_coef: float, seed: int,
-                              ent_step: int, row_offset: int, slab: torch.Tensor) -> None:
+                              ent_step: int, row_offset: int, slab: torch.Tensor, min_scale: float = 1e-3) -> None:
     """Fills slab (n_slab, stride) with partial [MLP gradient | d log_std | actor_loss, entropy] sums."""
     _req(agents_view, torch.float32, "agents_view")
     rows, din = agents_view.shape
@@ -308,7 +308,7 @@ def ppo_actor_grad_continuous(params, agents_view, action, old_log_prob, advanta
     if slab.dim() != 2 or slab.shape[1] < P + 2:
         raise ValueError("slab must be (n_slab, >= P+2)")
     check(
-        lib().mava_ppo_actor_grad_continuous_f32(ptr(params), din, action_dim, ptr(agents_view), ptr(action),
+        lib().mava_ppo_actor_grad_continuous_f32(ptr(params), din, action_dim, float(min_scale), ptr(agents_view), ptr(action),
                                                  ptr(old_log_prob), ptr(advantages), ptr(stats), ptr(idx), idx_base,
                                                  Rb, A, clip_eps, ent_coef, seed & 0xFFFFFFFFFFFFFFFF,
                                                  ent_step & 0xFFFFFFFF, row_offset & 0xFFFFFFFF, ptr(slab),

@@ -94,6 +94,7 @@ class RecLearner:
         # rec_mappo.py:361-363: the action head of the configuration, sized by the env's action dimension
         action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
         self.continuous = type(action_head).__name__ == "ContinuousActionHead"
+        self.min_scale = float(getattr(action_head, "min_scale", 1e-3))
         if self.continuous and not getattr(action_head, "independent_std", True):
             raise NotImplementedError("ContinuousActionHead(independent_std=False) is built for the feed-forward systems "
                                       "(general network path), not for the recurrent ones")
@@ -264,13 +265,13 @@ class RecLearner:
                     rng_args = (self.seed & (2**64 - 1), step & 0xFFFFFFFF, ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0)
                     if packed:
                         launch("rec_step", lib().mava_rec_step_packed_f32, ptr(self.pack_a), ptr(self.pack_c),
-                               ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), None if self.continuous else ptr(rep.action_mask[t]),
+                               ptr(pa), self.Oa, self.nA, self.min_scale, ptr(rep.agents_view[t]), None if self.continuous else ptr(rep.action_mask[t]),
                                ptr(d_prev), ptr(rep.h_actor), ptr(rep.h_actor_next), EA, *rng_args,
                                None if self.continuous else ptr(rep.action[t]), ptr(rep.action[t]) if self.continuous else None,
                                ptr(rep.log_prob[t]), *critic_args)
                     elif self.continuous:
                         check(lib().mava_rec_step_continuous_f32(
-                            ptr(pa), self.Oa, self.nA, ptr(rep.agents_view[t]), ptr(d_prev), ptr(rep.h_actor),
+                            ptr(pa), self.Oa, self.nA, self.min_scale, ptr(rep.agents_view[t]), ptr(d_prev), ptr(rep.h_actor),
                             ptr(rep.h_actor_next), EA, *rng_args, ptr(rep.action[t]), ptr(rep.log_prob[t]), *critic_args),
                             "mava_rec_step_continuous_f32")
                     else:
@@ -293,7 +294,7 @@ class RecLearner:
                                                     A, training=False)
                 rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
                 if self.continuous:
-                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, ptr(ws.y), ptr(self.actor_network.log_std(pa)), None,
+                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, self.min_scale, ptr(ws.y), ptr(self.actor_network.log_std(pa)), None,
                                                                self.seed & (2**64 - 1), step & 0xFFFFFFFF,
                                                                ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]),
                                                                ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_continuous_f32")
@@ -372,7 +373,7 @@ class RecLearner:
                 assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
             elif self.continuous:
                 check(L.mava_seq_actor_loss_continuous_f32(
-                    T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
+                    T, Rm, E, A, self.nA, self.min_scale, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
                     ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
                     self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
                     self.grad_scale, ptr(ws.dy), None, ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")

@@ -434,7 +434,7 @@ class RecurrentActor(_RecurrentNet):
         flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
         h, logits = self._apply_sequence(flat, hstate, observation.agents_view, done)
         if self.continuous:
-            return h, TanhNormal(logits, self.log_std(flat.float()))
+            return h, TanhNormal(logits, self.log_std(flat.float()), self.action_head.min_scale)
         return h, Categorical(logits, observation.action_mask)
 
 

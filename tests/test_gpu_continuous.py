@@ -21,10 +21,23 @@ def _params(rng, din, dim, head_scale=1.0):
     return np.concatenate([mlp, rng.normal(size=dim) * 0.4]).astype(np.float32)
 
 
+@pytest.fixture(params=[1e-3, 0.05], ids=["min_scale=1e-3", "min_scale=0.05"])
+def min_scale(request, monkeypatch):
+    """ContinuousActionHead.min_scale (mava/networks.py:134,162): the reference's default and another value; the oracle
+    reads its module constant at call time."""
+    monkeypatch.setattr(tn, "MIN_SCALE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("rows,din,dim,share", [(64, 20, 2, 1), (1000, 31, 6, 1), (96, 50, 9, 4), (33, 7, 1, 1),
                                                 (16384, 22, 2, 4)])
-def test_continuous_policy_step_matches_oracle(dev, rows, din, dim, share):
-    from mava_amd import ops
+def test_continuous_policy_step_matches_oracle(dev, rows, din, dim, share, min_scale):
+    from functools import partial
+
+    from mava_amd import ops as _ops
+
+    class ops:  # every call of this test with the fixture's min_scale
+        policy_step_continuous = staticmethod(partial(_ops.policy_step_continuous, min_scale=min_scale))
 
     rng = np.random.default_rng(rows + dim)
     fa = _params(rng, din, dim)
@@ -69,7 +82,7 @@ def test_continuous_policy_step_matches_oracle(dev, rows, din, dim, share):
 @pytest.mark.parametrize("TE,A,O,dim,Rb,use_idx,n_slab", [(64, 4, 20, 2, 64, False, 3), (200, 2, 60, 6, 77, True, 8),
                                                           (96, 3, 100, 9, 40, True, 2), (33, 1, 7, 1, 33, True, 1),
                                                           (4096, 4, 22, 2, 2048, True, 256), (80, 2, 180, 4, 50, True, 3)])
-def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n_slab):
+def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n_slab, min_scale):
     from mava_amd import ops
 
     rng = np.random.default_rng(TE + dim)
@@ -92,7 +105,8 @@ def test_continuous_actor_grad_matches_oracle(dev, TE, A, O, dim, Rb, use_idx, n
     slab = torch.zeros((n_slab, P + 2), device=dev)
     stats = ops.adv_stats(_t(adv, dev), _t(idx, dev) if use_idx else None, 0, Rb, A)
     ops.ppo_actor_grad_continuous(_t(flat, dev), _t(av, dev), _t(action, dev), _t(old_lp, dev), _t(adv, dev), stats,
-                                  _t(idx, dev) if use_idx else None, 0, Rb, A, dim, 0.2, 0.01, seed, ent_step, off, slab)
+                                  _t(idx, dev) if use_idx else None, 0, Rb, A, dim, 0.2, 0.01, seed, ent_step, off, slab,
+                                  min_scale=min_scale)
     out = torch.zeros(P + 2, device=dev)
     ops.slab_reduce(slab, P + 2, out)
     torch.cuda.synchronize()

@@ -173,7 +173,7 @@ def test_generic_continuous_head(dev, independent, mode):
     dsp = torch.zeros((ws.loss_partials.shape[0], dim), device=dev)
     log_std_vec = flat_d[net.num_net_params :] if independent else None
     check(lib().mava_seq_actor_loss_continuous_f32(
-        1, Rm, E, A, dim, ptr(idx_d), ptr(outs[0]), ptr(log_std_vec), None if independent else ptr(outs[1]), ptr(act_d), ptr(olp_d),
+        1, Rm, E, A, dim, 1e-3, ptr(idx_d), ptr(outs[0]), ptr(log_std_vec), None if independent else ptr(outs[1]), ptr(act_d), ptr(olp_d),
         ptr(adv_d), ptr(stats), stats.shape[0], 0.2, 0.01, seed, ent_step, 0, gs, ptr(ws.dout[0]),
         None if independent else ptr(ws.dout[1]), ptr(ws.loss_partials), ptr(dsp), ws.loss_partials.shape[0], stream_ptr()), "loss")
     gw_d = torch.zeros(net.num_params, device=dev)

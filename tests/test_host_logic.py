@@ -36,8 +36,9 @@ def test_overrides():
                       ContinuousActionHead)
     assert isinstance(make_action_head(c.network.action_head, 5), DiscreteActionHead)
     assert ContinuousActionHead(3, independent_std=False).independent_std is False  # (runs on the general network path)
-    with pytest.raises(NotImplementedError):
-        ContinuousActionHead(3, min_scale=1e-2)
+    assert ContinuousActionHead(3, min_scale=1e-2).min_scale == 1e-2  # (a kernel argument since round 3: networks.py:134,162)
+    with pytest.raises(ValueError):
+        ContinuousActionHead(3, min_scale=-1.0)
     # network group swap to the CNN torsos (configs/network/cnn.yaml) and the general path's selection rule
     from mava_amd.generic_networks import CNNTorso, is_default_mlp, torso_from_config
 

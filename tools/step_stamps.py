@@ -20,7 +20,7 @@ ha, ha2 = torch.zeros(EA * 128, device=dev), torch.zeros(EA * 128, device=dev)
 hc, hc2 = torch.zeros(EA * 128, device=dev), torch.zeros(EA * 128, device=dev)
 act, lp, val = torch.zeros(EA, dtype=torch.int32, device=dev), torch.zeros(EA, device=dev), torch.zeros(EA, device=dev)
 def run():
-    check(L.mava_rec_step_packed_f32(ptr(pka), ptr(pkc), ptr(pa), Oa, nA, ptr(av), ptr(mask), ptr(done), ptr(ha), ptr(ha2), EA, 42, 0, 0, 0,
+    check(L.mava_rec_step_packed_f32(ptr(pka), ptr(pkc), ptr(pa), Oa, nA, 1e-3, ptr(av), ptr(mask), ptr(done), ptr(ha), ptr(ha2), EA, 42, 0, 0, 0,
                                      ptr(act), None, ptr(lp), ptr(pc), Oc, ptr(gs), 1, ptr(done), A, ptr(hc), ptr(hc2), E, A, ptr(val), stream_ptr()), "step")
 for _ in range(3): run()
 torch.cuda.synchronize()

@@ -138,9 +138,13 @@ def test_continuous_actor_grad_rejects_unsupported_shapes(dev):
 
 
 @pytest.mark.parametrize("system,U", [("ff_mappo", 2), ("ff_ippo", 1)])
-def test_continuous_learner_update_matches_oracle(dev, system, U):
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
+def test_continuous_learner_update_matches_oracle(dev, system, U, matmul):
     """The whole PPO update with network.action_head = ContinuousActionHead (the reference selects it with exactly this
-    override for MaBrax) on a MaBrax-shaped synthetic env, against the NumPy whole-update oracle."""
+    override for MaBrax) on a MaBrax-shaped synthetic env, against the NumPy whole-update oracle.  The continuous actor
+    runs the exact-f32 kernels in either mode; matmul selects the critic's arithmetic (f16x2: end-to-end tolerances of
+    tests/conftest.py:check_and_sync_f16x2_state)."""
+    from tests.conftest import check_and_sync_f16x2_state
     from mava_amd import envs
     from mava_amd.config import compose
     from mava_amd.systems.ppo import ff_ippo, ff_mappo
@@ -155,6 +159,7 @@ def test_continuous_learner_update_matches_oracle(dev, system, U):
     cfg.system.num_updates_per_eval = 2
     cfg.system.actor_lr = 1e-3
     cfg.system.critic_lr = 2e-3
+    cfg.system.matmul_mode = matmul
     central = system == "ff_mappo"
     mod = ff_mappo if central else ff_ippo
     env, eval_env = envs.make(cfg, add_global_state=central, device=dev)
@@ -185,9 +190,12 @@ def test_continuous_learner_update_matches_oracle(dev, system, U):
             assert_close(rep.value.cpu().numpy(), tr["value"], 1e-5, "values")
             assert_close(rep.adv.cpu().numpy(), tr["adv"], 1e-5, "advantages")
         assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
-        assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
-        assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
-        assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        if matmul == "f32":
+            assert_close(L.p[: L.Pa].cpu().numpy() - fa, ora.pa - fa, 2e-3, "actor update")
+            assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+            assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        else:
+            check_and_sync_f16x2_state(L, ora)
     # evaluator seam: the host distribution view agrees with the kernels' acting step
     from mava_amd.evaluator import get_eval_fn, make_ff_eval_act_fn
 

@@ -409,6 +409,7 @@ class RecurrentActor(_RecurrentNet):
                  hidden_state_dim: int = 128, obs_shape=None):
         super().__init__(obs_dim, action_head.action_dim, hidden_state_dim, pre_torso, post_torso, obs_shape)
         self.continuous = isinstance(action_head, ContinuousActionHead)
+        self.action_head = action_head
         if self.continuous:
             self.num_params += self.n_out
 

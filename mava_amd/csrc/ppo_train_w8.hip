@@ -19,9 +19,13 @@
 // A[i][4 kg + j], B[4 kg + j][i] - so an accumulator tile IS the B operand of a 16-deep product (the head).
 //
 // LDS images: [rows][128 features] f16, hi and lo plane, 256-byte rows, 16-byte chunk c of row r at chunk c ^ sw(r),
-// sw(r) = ((r & 3) << 1) | (((r >> 3) & 1) << 3): conflict-free for the row reads of the 16x16x32 B operand
+// sw(r) = ((r & 3) << 1) | (9 * ((r >> 3) & 1)): conflict-free for the row reads of the 16x16x32 B operand
 // (ds_read_b128, lanes (n, kg): row n, chunk 4 s + kg) AND for its hardware-transposed reads (ds_read_b64_tr_b16, two
-// 4-row blocks 8 rows apart per 32-lane half) - the swizzle (b) of cdna_hip_programming.md T10 is 2-way on the former.
+// 4-row blocks 8 rows apart per 32-lane half) - the swizzle (b) of cdna_hip_programming.md T10 is 2-way on the former -
+// and 2-way (8 LDS-array cycles for a 6-cycle instruction) on the 8-byte image stores of an accumulator tile (16 lanes =
+// 16 rows of one 8-byte column; banks are mod 32 dwords for stores), where sw without the bit 0 term is 4-way (16 cycles:
+// with eight waves storing at once that was ~1.3 K LDS-array cycles per tile; tools/lds_swizzle_search.py has the bank
+// model and the search over the linear maps).
 #include "h2_core.h"
 #include "ppo_train_task.h"
 #include "ctx.h"
@@ -84,7 +88,7 @@ constexpr int WIMG = 2 * WPLANE32;     // hi + lo
 constexpr int W2PLANE = 128 * WROW;
 constexpr int DYROW = 48;              // [32 rows][16 outputs] f16 + 16 bytes: conflict-free 8-byte row reads
 constexpr int DYPLANE = 32 * DYROW;
-__host__ __device__ inline int w8_sw(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+__host__ __device__ inline int w8_sw(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) * 9); }
 __host__ __device__ inline int w8_off(int row, int chunk) { return WROW * row + 16 * (chunk ^ w8_sw(row)); }
 
 struct W8Layout {

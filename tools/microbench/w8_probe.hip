@@ -3,7 +3,7 @@
 //   2. v_mfma_f32_16x16x16_f16: A[i][4 kg + j], B[4 kg + j][i], j = 0..3; same C map
 //   3. an accumulator tile of (1) as the B operand of (2): B[k = 4 kg + r][n = i] IS register r of lane (i, kg)
 //   4. the swizzled image of the kernel ([rows][128 halves], 256-byte rows, 16-byte chunk c of row r stored at chunk
-//      c ^ sw(r), sw(r) = ((r & 3) << 1) | (((r >> 3) & 1) << 3)): the row read of the 16x16x32 B operand (lane (n, kg), step s:
+//      c ^ sw(r), sw(r) = ((r & 3) << 1) | (9 * ((r >> 3) & 1))): the row read of the 16x16x32 B operand (lane (n, kg), step s:
 //      row 16 nt + n, halves 32 s + 8 kg .. + 7 = chunk 4 s + kg) and the hardware-transposed read of the 16x16x32 A operand
 //      (lane (m, kg): column 16 t + m of rows 8 kg .. 8 kg + 7: two ds_read_b64_tr_b16, lane 4q + p of a 16-lane group
 //      supplies row 8 kg + q (+ 4), halves 16 t + 4 p .. + 3 = chunk 2 t + (p >> 1), byte 8 (p & 1))
@@ -16,7 +16,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS3(p) ((__attribute__((address_space(3))) s16x4*)(p))
-__device__ __host__ inline int sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
+__device__ __host__ inline int sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) * 9); }
 __device__ __host__ inline int off(int r, int c) { return 256 * r + 16 * (c ^ sw(r)); }  // bytes
 
 __global__ void probe(const float* A32, const float* B32, const float* A16, float* c32, float* c16, float* y16, float* rowr, float* trr) {

@@ -176,6 +176,16 @@ class RecLearner:
                             else os.environ.get("MAVA_RCCL_CUS", "8" if self.world > 1 else "0"))
         n_slab = max(1, min(NUM_CU - max(0, min(self.rccl_cus, NUM_CU - 1)), (self.T * self.Rm) // 32))
         self.slabs = torch.zeros((n_slab, H * 3 * H + 3 * H + 8), device=d)
+        # The two networks are independent between the parameters of one Adam step and the next (rec_mappo.py:210-266 computes
+        # both losses from the same params): the critic's forward / loss / backward runs on a second stream with its own
+        # workspace and slabs, under the actor's.  Its once-per-env scans fill one CU in eight (32 workgroups at config 4)
+        # and its products are short launches - alone on the device they left it mostly idle for ~14 ms per update.
+        self.overlap_critic = (os.environ.get("MAVA_REC_OVERLAP", "1") != "0" and d.type == "cuda" and not self.generic_nets)
+        if self.overlap_critic:
+            c_rows = self.T * (self.Rmc if self.critic_agg else self.Rm)
+            self.ws_c = RecWorkspace(c_rows, 1, d, training=True, din_max=self.Oc)
+            self.slabs_c = torch.zeros_like(self.slabs)
+            self.side = torch.cuda.Stream(device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
         self.perm_count = 0  # epoch permutations drawn so far (counter of mava_permutation_i32)
@@ -355,61 +365,82 @@ class RecLearner:
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         idx = perm[mb * Em : (mb + 1) * Em].contiguous()
         flat_rows = (self._t_range + idx[None, :].long()).reshape(-1).to(torch.int32)  # (t*E + env) rows of the minibatch
-        ws, L, st = self.ws, lib(), stream_ptr()
-        nblk = ws.loss_partials.shape[0]
+        L = lib()
         # f16x2: the output path (post_torso -> head -> loss -> backward) of both networks runs as ONE launch each
         # (mava_rec_out_f32); the continuous head and more than 16 actions stay on the layer-wise kernels
         fused_out = self.fused_out
-        for u, rep in enumerate(self.reps):
-            acc = u > 0
-            # ---- actor (rec_mappo.py:210-242)
-            self.actor_network.forward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, rep.h0_actor, False, idx, T, Rm, E, A,
-                                                training=True, stop_after_scan=fused_out)
-            ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
-            if fused_out:
-                ok = self.actor_network.fused_output(pa, ws, idx, T, Rm, E, A, 1, True, rep.action_mask[:T], rep.action, rep.log_prob,
-                                                     rep.adv, self.stats, float(s.clip_eps), float(s.ent_coef), self.slabs,
-                                                     self.g[: self.Pa], self.g[self.P : self.P + 2], acc, self.grad_scale)
-                assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
-            elif self.continuous:
-                check(L.mava_seq_actor_loss_continuous_f32(
-                    T, Rm, E, A, self.nA, self.min_scale, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
-                    ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
-                    self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
-                    self.grad_scale, ptr(ws.dy), None, ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
-                ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
-            else:
-                check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
-                                                ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0],
-                                                float(s.clip_eps), float(s.ent_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
-                                                nblk, st),
-                      "mava_seq_actor_loss_f32")
-            if not fused_out:
-                ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
-            self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, self.slabs,
-                                                 self.g[: self.Pa], accumulate=acc, grad_scale=self.grad_scale, from_scan=fused_out)
-            # ---- critic (rec_mappo.py:244-266)
-            cx = self._critic_x(rep, 0, T)
-            if self.critic_agg:  # E-row sequences: kernel view (E envs x 1 "agent"), A agent slots per row in the loss
-                c_share, c_done, c_Rm, c_A, c_apr = 1, rep.done_env_in, self.Rmc, 1, A
-            else:
-                c_share, c_done, c_Rm, c_A, c_apr = self.critic_share, rep.done_in, Rm, A, 1
-            self.critic_network.forward_sequence(pc, ws, cx, c_share, c_done, rep.h0_critic, False, idx, T, c_Rm, E, c_A,
-                                                 training=True, stop_after_scan=fused_out)
-            if fused_out:
-                ok = self.critic_network.fused_output(pc, ws, idx, T, c_Rm, E, c_A, c_apr, False, None, None, rep.value, rep.tgt, None,
-                                                      float(s.clip_eps), float(s.vf_coef), self.slabs, self.g[self.Pa : self.P],
-                                                      self.g[self.P + 2 : self.P + 3], acc, self.grad_scale)
-                assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
-            else:
-              check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
-                                               float(s.clip_eps), float(s.vf_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
-                                               nblk, st),
-                    "mava_seq_critic_loss_f32")
-              ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
-            self.critic_network.backward_sequence(pc, ws, cx, c_share, c_done, idx, T, c_Rm, E, c_A, self.slabs,
-                                                  self.g[self.Pa : self.P], accumulate=acc, grad_scale=self.grad_scale,
-                                                  from_scan=fused_out)
+
+        def actor_part(ws, slabs):
+            """rec_mappo.py:210-242 for every replica, on the current stream."""
+            st = stream_ptr()
+            nblk = ws.loss_partials.shape[0]
+            for u, rep in enumerate(self.reps):
+                acc = u > 0
+                self.actor_network.forward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, rep.h0_actor, False, idx, T, Rm, E, A,
+                                                    training=True, stop_after_scan=fused_out)
+                ops.adv_stats(rep.adv.view(-1), flat_rows, 0, T * Em, A, out=self.stats)
+                if fused_out:
+                    ok = self.actor_network.fused_output(pa, ws, idx, T, Rm, E, A, 1, True, rep.action_mask[:T], rep.action, rep.log_prob,
+                                                         rep.adv, self.stats, float(s.clip_eps), float(s.ent_coef), slabs,
+                                                         self.g[: self.Pa], self.g[self.P : self.P + 2], acc, self.grad_scale)
+                    assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
+                elif self.continuous:
+                    check(L.mava_seq_actor_loss_continuous_f32(
+                        T, Rm, E, A, self.nA, self.min_scale, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
+                        ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
+                        self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
+                        self.grad_scale, ptr(ws.dy), None, ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
+                    ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
+                else:
+                    check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
+                                                    ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0],
+                                                    float(s.clip_eps), float(s.ent_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
+                                                    nblk, st),
+                          "mava_seq_actor_loss_f32")
+                if not fused_out:
+                    ops.slab_reduce(ws.loss_partials, 2, self.g[self.P : self.P + 2], accumulate=acc)
+                self.actor_network.backward_sequence(pa, ws, rep.agents_view[:T], 1, rep.done_in, idx, T, Rm, E, A, slabs,
+                                                     self.g[: self.Pa], accumulate=acc, grad_scale=self.grad_scale, from_scan=fused_out)
+
+        def critic_part(ws, slabs):
+            """rec_mappo.py:244-266 for every replica, on the current stream."""
+            st = stream_ptr()
+            nblk = ws.loss_partials.shape[0]
+            for u, rep in enumerate(self.reps):
+                acc = u > 0
+                cx = self._critic_x(rep, 0, T)
+                if self.critic_agg:  # E-row sequences: kernel view (E envs x 1 "agent"), A agent slots per row in the loss
+                    c_share, c_done, c_Rm, c_A, c_apr = 1, rep.done_env_in, self.Rmc, 1, A
+                else:
+                    c_share, c_done, c_Rm, c_A, c_apr = self.critic_share, rep.done_in, Rm, A, 1
+                self.critic_network.forward_sequence(pc, ws, cx, c_share, c_done, rep.h0_critic, False, idx, T, c_Rm, E, c_A,
+                                                     training=True, stop_after_scan=fused_out)
+                if fused_out:
+                    ok = self.critic_network.fused_output(pc, ws, idx, T, c_Rm, E, c_A, c_apr, False, None, None, rep.value, rep.tgt, None,
+                                                          float(s.clip_eps), float(s.vf_coef), slabs, self.g[self.Pa : self.P],
+                                                          self.g[self.P + 2 : self.P + 3], acc, self.grad_scale)
+                    assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
+                else:
+                    check(L.mava_seq_critic_loss_f32(T, c_Rm, E, c_A, c_apr, ptr(idx), ptr(ws.y), ptr(rep.value), ptr(rep.tgt),
+                                                     float(s.clip_eps), float(s.vf_coef), self.grad_scale, ptr(ws.dy), ptr(ws.loss_partials),
+                                                     nblk, st),
+                          "mava_seq_critic_loss_f32")
+                    ops.slab_reduce(ws.loss_partials, 1, self.g[self.P + 2 : self.P + 3], accumulate=acc)
+                self.critic_network.backward_sequence(pc, ws, cx, c_share, c_done, idx, T, c_Rm, E, c_A, slabs,
+                                                      self.g[self.Pa : self.P], accumulate=acc, grad_scale=self.grad_scale,
+                                                      from_scan=fused_out)
+
+        from . import _lib as _l
+        if self.overlap_critic and _l.TIMERS is None:  # (bench.py's per-kernel timers measure the kernels one at a time)
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)  # parameters of the last Adam step, idx, advantages / targets
+            with torch.cuda.stream(self.side):
+                critic_part(self.ws_c, self.slabs_c)
+            actor_part(self.ws, self.slabs)
+            main.wait_stream(self.side)
+        else:
+            actor_part(self.ws, self.slabs)
+            critic_part(self.ws, self.slabs)
         parallel.allreduce_sum_(self.g)
         ops.clip_adam(self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),

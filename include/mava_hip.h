@@ -270,8 +270,10 @@ int mava_rec_dense_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, cons
  * y_ld (<= 0: N) = features per y tile (y + 32 * n0 reads a column block of a wider matrix).
  * out_scale undoes the grad_scale the backward chain was started with (1.0f when none). */
 int mava_rec_xty_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A,
-                     int x_share, int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
-                     float* slab, long slab_stride, int n_slab, mava_stream_t s);
+                     int x_share, int x_ld, const float* y, int y_ld, const float* y_tail, int y_split, int y_tail_ld, int K, int N,
+                     int rows, int want_bias, float out_scale, float* slab, long slab_stride, int n_slab, mava_stream_t s);
+/* (y_tail, round 3: when not NULL, features [y_split, N) of Y are features [0, N - y_split) of the T32 matrix y_tail with
+ * y_tail_ld features per tile; y_split a multiple of 32.  The BPTT scan's dgh is [dgi's r and z thirds | its own n third].) */
 /* Row-major, env-permuted observation slice of a minibatch (same gather description as mava_rec_dense_f32 with
  * x_rowmajor) -> T32 matrix `out` with k_pad >= K features per tile (zeros past K): done once per minibatch, read by
  * the pre-torso product and by its weight-gradient product as a plain T32 operand. */
@@ -289,7 +291,10 @@ int mava_gru_scan_fwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, cons
  * writes dgi and dgh (T32, T*Rm x 384: gradients w.r.t. the input-side and hidden-side gate pre-activations). */
 int mava_gru_scan_bwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                           const float* wh, const float* saved, const float* hprev, const float* dh_out,
-                          float* dgi, float* dgh, mava_stream_t s);
+                          float* dgi, float* dgh, int dgh_n_only, mava_stream_t s);
+/* (dgh_n_only != 0: dgh is T32 (T*Rm x 128) and receives the n third of the hidden-side gate gradient alone - its r and z
+ * thirds equal dgi's, since the gates add the two pre-activations (flax GRUCell); the scan is HBM-bound, the two thirds
+ * were a sixth of its traffic.) */
 
 /* sequence losses on T32 logits / values: rec_mappo.py:210-242 and :244-266 (after the re-unroll);
  * loss_partials: (n_blocks, 2) partial sums already divided by the element count.  The gradient w.r.t. the network

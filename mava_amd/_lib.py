@@ -63,10 +63,10 @@ _SIGNATURES = {
     "mava_synth_rware_step": [i32, i32, i32, i32, i32, i32, i32, u64, u32, vp, u32, i32] + [vp] * 14 + [vp, i32, vp],
     "mava_rollout_ff_f32": [vp, i32, vp, i32, i32, i32, i32, i32, i32, u64, u64, u32, u32, u32, i32] + [vp] * 18 + [vp, vp, f32, f32, vp],
     "mava_rec_dense_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mava_rec_xty_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
+    "mava_rec_xty_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
     "mava_rec_gather_t32_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mava_gru_scan_fwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
-    "mava_gru_scan_bwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "mava_gru_scan_bwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_continuous_f32": [vp, i32, i32, f32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp],
     "mava_rec_step_f32": [vp, i32, i32, vp, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp,

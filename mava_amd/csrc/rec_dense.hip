@@ -311,10 +311,13 @@ __global__ __launch_bounds__(256, 1) void rec_xty_kernel(XtyTask tk) {
   const int nx4 = K * 8, ny4 = N * 8;  // float4 per tile
   auto issue = [&](int it) {
     const float4* ysrc = reinterpret_cast<const float4*>(tk.y + ((long)it * tk.y_ld) * 32);
+    const float4* ytail = reinterpret_cast<const float4*>(tk.y_tail + ((long)it * tk.y_tail_ld) * 32);
+    const int ysp4 = tk.y_tail ? tk.y_split * 8 : ny4;  // features past y_split come from y_tail (a multiple of 32 features: warp-uniform)
 #pragma unroll
     for (int i = 0; i < NT_ALL; ++i) {
       const int q = tid + 256 * i;
-      yq[i] = ysrc[q < ny4 ? q : (ny4 - 1)];
+      const int qq = q < ny4 ? q : (ny4 - 1);
+      yq[i] = qq < ysp4 ? ysrc[qq] : ytail[qq - ysp4];
     }
     if (!tk.x_rowmajor) {
       const float4* xsrc = reinterpret_cast<const float4*>(tk.x + ((long)it * tk.x_ld) * 32);
@@ -505,8 +508,8 @@ extern "C" int mava_rec_dense_f32(const mava_ctx* ctx, const float* x, int x_row
 }
 
 extern "C" int mava_rec_xty_f32(const mava_ctx* ctx, const float* x, int x_rowmajor, const int32_t* idx, int Rm, int E, int A, int x_share,
-                                int x_ld, const float* y, int y_ld, int K, int N, int rows, int want_bias, float out_scale,
-                                float* slab, long slab_stride, int n_slab, hipStream_t s) {
+                                int x_ld, const float* y, int y_ld, const float* y_tail, int y_split, int y_tail_ld, int K, int N,
+                                int rows, int want_bias, float out_scale, float* slab, long slab_stride, int n_slab, hipStream_t s) {
   if (!x_rowmajor && x_ld <= 0) x_ld = K;
   if (y_ld <= 0) y_ld = N;
   MAVA_ARG_CHECK(y_ld >= N, 6, "mava_rec_xty_f32: y_ld=%d < N=%d", y_ld, N);
@@ -516,7 +519,10 @@ extern "C" int mava_rec_xty_f32(const mava_ctx* ctx, const float* x, int x_rowma
   MAVA_ARG_CHECK(slab_stride >= (long)K * N + (want_bias ? N : 0), 2, "mava_rec_xty_f32: slab_stride too small");
   MAVA_ARG_CHECK(x && y && slab, 3, "mava_rec_xty_f32: null pointer argument");
   MAVA_ARG_CHECK(x_ld >= K, 5, "mava_rec_xty_f32: x_ld=%d < K=%d", x_ld, K);
-  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, y_ld, slab, slab_stride, want_bias, out_scale};
+  MAVA_ARG_CHECK(y_tail == nullptr || (y_split >= 32 && y_split % 32 == 0 && y_split < N && y_tail_ld >= N - y_split), 10,
+                 "mava_rec_xty_f32: y_tail with y_split=%d y_tail_ld=%d N=%d", y_split, y_tail_ld, N);
+  XtyTask tk = {x, x_rowmajor, idx, Rm, E, A, x_share, x_ld, y, K, N, rows, y_ld, slab, slab_stride, want_bias, out_scale,
+                y_tail, y_tail ? y_split : N, y_tail_ld};
   if (mava_ctx_matmul_mode(ctx) == 1) {
     const int rc = mava_rec_xty_h2_launch(tk, n_slab, s);
     if (rc <= 0) return rc;

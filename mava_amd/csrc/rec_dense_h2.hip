@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, h = lane >> 5, j = lane & 31;
   const int K = tk.K, N = tk.N;
-  const int nx4 = K * 8, ny4 = N * 8;
+  const int nx4 = K * 8, ny4 = N * 8, ysp4 = tk.y_split * 8;
 
   f32x16 acc[KT][NTW];
 #pragma unroll
@@ -318,9 +318,13 @@ __global__ __launch_bounds__(256, 1) void rec_xty_h2_kernel(XtyTask tk) {
       const int q = tid + 256 * k;
       raw[k] = xs[q < nx4 ? q : (nx4 - 1)];
     } else {
-      const float4* ys = reinterpret_cast<const float4*>(tk.y + (long)it * tk.y_ld * 32);
       const int q = tid + 256 * (k - KT);
-      raw[k] = ys[q < ny4 ? q : (ny4 - 1)];
+      const int qq = q < ny4 ? q : (ny4 - 1);
+      if (tk.y_tail != nullptr && qq >= ysp4) {  // (wave-uniform: y_split is a multiple of 32 features = 256 float4)
+        raw[k] = reinterpret_cast<const float4*>(tk.y_tail + (long)it * tk.y_tail_ld * 32)[qq - ysp4];
+      } else {
+        raw[k] = reinterpret_cast<const float4*>(tk.y + (long)it * tk.y_ld * 32)[qq];
+      }
     }
   };
   // Branch-free: slots past K / N stage clamped duplicates into feature rows whose products are never stored.

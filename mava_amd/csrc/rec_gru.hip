@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
     const bool rs = tk.done[ext_row(tk, t, m)] != 0;
     float dhp[16];
     float* const gi_o = tk.dgi + tile * G3 * 32 + lane_off;
-    float* const gh_o = tk.dgh + tile * G3 * 32 + lane_off;
+    float* const gh_o = tk.dgh + tile * (tk.dgh_n_only ? MLP_H : G3) * 32 + lane_off;
     float* const dgl = DG + fb * LDT + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -200,9 +200,13 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_kernel(ScanTask tk) {
       gi_o[OFF(r)] = dr_pre;
       gi_o[MLP_H * 32 + OFF(r)] = dz_pre;
       gi_o[2 * MLP_H * 32 + OFF(r)] = dn_pre;
-      gh_o[OFF(r)] = dr_pre;
-      gh_o[MLP_H * 32 + OFF(r)] = dz_pre;
-      gh_o[2 * MLP_H * 32 + OFF(r)] = dghn;
+      if (tk.dgh_n_only) {  // (block-uniform) the n third alone: r and z thirds are dgi's
+        gh_o[OFF(r)] = dghn;
+      } else {
+        gh_o[OFF(r)] = dr_pre;
+        gh_o[MLP_H * 32 + OFF(r)] = dz_pre;
+        gh_o[2 * MLP_H * 32 + OFF(r)] = dghn;
+      }
       dgl[fo] = dr_pre;
       dgl[MLP_H * LDT + fo] = dz_pre;
       dgl[2 * MLP_H * LDT + fo] = dghn;
@@ -570,7 +574,7 @@ extern "C" int mava_gru_scan_fwd_f32(const mava_ctx* ctx, int T, int Rm, int E, 
 
 extern "C" int mava_gru_scan_bwd_f32(const mava_ctx* ctx, int T, int Rm, int E, int A, const int32_t* idx, const uint8_t* done,
                                      const float* wh, const float* saved, const float* hprev,
-                                     const float* dh_out, float* dgi, float* dgh, hipStream_t s) {
+                                     const float* dh_out, float* dgi, float* dgh, int dgh_n_only, hipStream_t s) {
   MAVA_ARG_CHECK(T >= 1 && Rm >= 32 && Rm % 32 == 0 && E >= 1 && A >= 1 && Rm % A == 0, 0,
                  "mava_gru_scan_bwd_f32: T=%d Rm=%d E=%d A=%d", T, Rm, E, A);
   MAVA_ARG_CHECK(done && wh && saved && hprev && dh_out && dgi && dgh, 1,
@@ -578,7 +582,7 @@ extern "C" int mava_gru_scan_bwd_f32(const mava_ctx* ctx, int T, int Rm, int E, 
   ScanTask tk = {};
   tk.T = T; tk.Rm = Rm; tk.E = E; tk.A = A; tk.idx = idx; tk.done = done; tk.wh = wh;
   tk.saved = const_cast<float*>(saved); tk.hprev = const_cast<float*>(hprev); tk.dh_out = dh_out;
-  tk.dgi = dgi; tk.dgh = dgh;
+  tk.dgi = dgi; tk.dgh = dgh; tk.dgh_n_only = dgh_n_only != 0;
   if (mava_ctx_matmul_mode(ctx) == 1) return mava_gru_scan_bwd_h2_launch(tk, s);  // rec_gru_h2.hip
   hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(Rm / 32), dim3(256), 0, s, tk);
   MAVA_LAUNCH_CHECK();

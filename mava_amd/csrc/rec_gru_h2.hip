@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd_h2_kernel(ScanTask tk) {
 #endif
 }
 
+template <bool NONLY>
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
   extern __shared__ __attribute__((aligned(16))) u8 DIMG[];  // 2 x GIMG
   const int tid = threadIdx.x;
@@ -271,7 +272,9 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
     const bool rs = ((dbits >> (t & 31)) & 1u) != 0;
     float dhp[16], g_r[16], g_z[16], g_n[16];
     float* const gi_o = tk.dgi + tile * G3 * 32 + lane_off;
-    float* const gh_o = tk.dgh + tile * G3 * 32 + lane_off;
+    // dgh's r and z thirds are dgi's (the gates add the two pre-activations): NONLY stores the n third alone, 10 instead
+    // of 12 row-steps x 512 bytes of traffic per step of this HBM-bound kernel; the consumer reads the thirds where they are
+    float* const gh_o = tk.dgh + tile * (NONLY ? MLP_H : G3) * 32 + lane_off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float rr = i_r[r], zz = i_z[r], nn = i_n[r], hl = i_hl[r], hp = i_hp[r];
@@ -287,9 +290,13 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_h2_kernel(ScanTask tk) {
       gi_o[OFFW(r)] = dr_pre;
       gi_o[MLP_H * 32 + OFFW(r)] = dz_pre;
       gi_o[2 * MLP_H * 32 + OFFW(r)] = dn_pre;
-      gh_o[OFFW(r)] = dr_pre;
-      gh_o[MLP_H * 32 + OFFW(r)] = dz_pre;
-      gh_o[2 * MLP_H * 32 + OFFW(r)] = dghn;
+      if constexpr (NONLY) {
+        gh_o[OFFW(r)] = dghn;
+      } else {
+        gh_o[OFFW(r)] = dr_pre;
+        gh_o[MLP_H * 32 + OFFW(r)] = dz_pre;
+        gh_o[2 * MLP_H * 32 + OFFW(r)] = dghn;
+      }
       g_r[r] = dr_pre;
       g_z[r] = dz_pre;
       g_n[r] = dghn;
@@ -336,10 +343,12 @@ int mava_gru_scan_fwd_h2_launch(const ScanTask& tk, hipStream_t s) {
 int mava_gru_scan_bwd_h2_launch(const ScanTask& tk, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)gru_scan_bwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GIMG));
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)gru_scan_bwd_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GIMG));
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)gru_scan_bwd_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GIMG));
     attr_set = true;
   }
-  hipLaunchKernelGGL(gru_scan_bwd_h2_kernel, dim3(tk.Rm / 32), dim3(256), 2 * GIMG, s, tk);
+  if (tk.dgh_n_only) hipLaunchKernelGGL(gru_scan_bwd_h2_kernel<true>, dim3(tk.Rm / 32), dim3(256), 2 * GIMG, s, tk);
+  else hipLaunchKernelGGL(gru_scan_bwd_h2_kernel<false>, dim3(tk.Rm / 32), dim3(256), 2 * GIMG, s, tk);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

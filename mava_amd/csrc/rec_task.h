@@ -43,6 +43,9 @@ struct XtyTask {
   long slab_stride;
   int want_bias;
   float out_scale;     // dW and db are multiplied by this at the slab write (the backward chain runs in scaled units)
+  const float* y_tail; // null, or T32 (rows x y_tail_ld): features [y_split, N) of Y are its features [0, N - y_split)
+  int y_split;         // (a multiple of 32: the BPTT scan's dgh = [dgi's r and z thirds | its own n third])
+  int y_tail_ld;
 };
 
 
@@ -62,7 +65,8 @@ struct ScanTask {
   // backward
   const float* dh_out;       // T32 (T*Rm x 128)
   float* dgi;                // T32 (T*Rm x 384)
-  float* dgh;                // T32 (T*Rm x 384)
+  float* dgh;                // T32 (T*Rm x 384), or (T*Rm x 128) = its n third alone when dgh_n_only (r and z thirds == dgi's)
+  int dgh_n_only;
 };
 
 __device__ __forceinline__ long ext_row(const ScanTask& tk, int t, int m) {

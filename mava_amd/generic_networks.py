@@ -196,8 +196,10 @@ class GenericNet:
                        y.data_ptr() + 4 * 32 * n0, N, kb, nb, rows, 0, s)
 
     def _xty(self, x_ptr: int, x_ld: int, K: int, y: torch.Tensor, N: int, rows: int, slabs: torch.Tensor, gw: torch.Tensor,
-             gb: Optional[torch.Tensor], scale: float, accumulate: bool, gb_accumulate: Optional[bool] = None) -> None:
-        """gw (K x N) (+)= scale * x^T y ; gb (N) (+)= scale * colsum(y)"""
+             gb: Optional[torch.Tensor], scale: float, accumulate: bool, gb_accumulate: Optional[bool] = None,
+             y_tail: Optional[torch.Tensor] = None, y_split: int = 0) -> None:
+        """gw (K x N) (+)= scale * x^T y ; gb (N) (+)= scale * colsum(y).  y_tail: T32 (rows x (N - y_split)) holding the
+        features of y from y_split on (a multiple of 128: the column blocks below never straddle it)."""
         from . import ops
 
         L, s = lib(), stream_ptr()
@@ -206,8 +208,12 @@ class GenericNet:
             for k0 in range(0, K, 128):
                 kb = min(128, K - k0)
                 want_b = int(gb is not None and k0 == 0)
-                launch("gen_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, y.data_ptr() + 4 * 32 * n0, N, kb, nb,
-                       rows, want_b, scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
+                if y_tail is not None and n0 >= y_split:
+                    y_ptr, y_ld = y_tail.data_ptr() + 4 * 32 * (n0 - y_split), N - y_split
+                else:
+                    y_ptr, y_ld = y.data_ptr() + 4 * 32 * n0, N
+                launch("gen_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr + 4 * 32 * k0, 0, None, 0, 0, 0, 1, x_ld, y_ptr, y_ld, None, 0, 0,
+                       kb, nb, rows, want_b, scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
                 blk = torch.empty(kb * nb, device=y.device)
                 ops.slab_reduce(slabs, kb * nb, blk)
                 dst = gw.view(K, N)[k0 : k0 + kb, n0 : n0 + nb]

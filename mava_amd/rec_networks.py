@@ -49,7 +49,7 @@ class RecWorkspace:
         self.xpre, self.gi, self.hs, self.post, self.y = f(H), f(G3), f(H), f(H), f(n_out_max)
         if training:
             self.hprev, self.saved = f(H), f(4 * H)
-            self.dy, self.dpost, self.dh_out, self.dgi, self.dgh, self.dxpre = f(n_out_max), f(H), f(H), f(G3), f(G3), f(H)
+            self.dy, self.dpost, self.dh_out, self.dgi, self.dgh, self.dxpre = f(n_out_max), f(H), f(H), f(G3), f(H), f(H)  # (dgh: n third)
             self.loss_partials = torch.zeros((1024, 2), device=device)  # one partial per loss-kernel block (4 blocks per CU)
 
 
@@ -339,15 +339,15 @@ class _RecurrentNet:
             gpost = grad_out[self.post_off : self.post_off + self.post.num_params]
             self.post.backward(fpost, wpost, [ws.dy], gpost, accumulate, grad_scale, dx_out=ws.dh_out)
             launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
-                   ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
+                   ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), 1, s)  # (dgh: the n third alone)
             o = lambda n: self.off[n][0]
             Np = self.Np
             self.pre._xty(wpre.feat_in.data_ptr(), Np, Np, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * G3],
                             grad_out[o("bi") : o("bi") + G3], 1.0 / grad_scale, accumulate)
             # dW_h, and db_hn = the n part of colsum(dgh) (taken from a scratch vector: r and z have no hidden-side bias)
             tmp_b = torch.empty(G3, device=flat.device)
-            self.pre._xty(ws.hprev.data_ptr(), H, H, ws.dgh, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
-                            1.0 / grad_scale, accumulate, gb_accumulate=False)
+            self.pre._xty(ws.hprev.data_ptr(), H, H, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
+                            1.0 / grad_scale, accumulate, gb_accumulate=False, y_tail=ws.dgh, y_split=2 * H)
             gbhn = grad_out[o("bhn") : o("bhn") + H]
             if accumulate:
                 gbhn.add_(tmp_b[2 * H :])
@@ -368,13 +368,14 @@ class _RecurrentNet:
             d(n_out, H, ws.dy, WheadT, H, ws.post, ws.dpost)        # d post pre-activation (relu mask = post > 0)
             d(H, H, ws.dpost, WpostT, H, None, ws.dh_out)           # gradient reaching h_t from the output path
         launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")), ptr(ws.saved),
-               ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), s)
+               ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), 1, s)  # (dgh: the n third alone, r and z thirds are dgi's)
         d(G3, H, ws.dgi, WiT, H, ws.xpre, ws.dxpre)             # d pre-torso pre-activation
 
-        def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0):
-            """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb]"""
-            launch("rec_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0, K, N,
-                   rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
+        def xty(x_ptr, x_rowmajor, x_ld, K, N, y, w_off, b_off, nb, xs=1, bias_slice=0, y_tail=None, y_split=0):
+            """grad[w_off : w_off + K*N] (+)= X^T Y ; grad[b_off : b_off + nb] (+)= colsum(Y)[bias_slice : bias_slice + nb];
+            Y's features from y_split on are those of y_tail (T32, N - y_split features per tile) when given"""
+            launch("rec_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0,
+                   ptr(y_tail), y_split, N - y_split, K, N, rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
             ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
             if b_off is not None:
                 tail = slabs[:, K * N + bias_slice : K * N + bias_slice + nb].contiguous()
@@ -385,7 +386,8 @@ class _RecurrentNet:
             xty(ptr(ws.post), 0, H, H, n_out, ws.dy, o("Whead"), o("bhead"), n_out)
             xty(ptr(ws.hs), 0, H, H, H, ws.dpost, o("Wpost"), o("bpost"), H)
         xty(ptr(ws.xpre), 0, H, H, G3, ws.dgi, o("Wi"), o("bi"), G3)
-        xty(ptr(ws.hprev), 0, H, H, G3, ws.dgh, o("Wh"), o("bhn"), H, bias_slice=2 * H)  # db_hn: n-part of colsum(dgh)
+        # dgh = [dgi's r and z thirds | ws.dgh]; db_hn: n-part of its column sums
+        xty(ptr(ws.hprev), 0, H, H, G3, ws.dgi, o("Wh"), o("bhn"), H, bias_slice=2 * H, y_tail=ws.dgh, y_split=2 * H)
         t32_in = ws.xin is not None and (self.ctx is not None and self.ctx.matmul_mode == "f16x2")  # the forward pass left the gathered input in ws.xin
         kp = -(-self.din // 32) * 32
         k0 = 0

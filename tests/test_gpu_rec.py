@@ -104,7 +104,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, rec_mode):
     dy = rng.standard_normal((rows, N)).astype(np.float32)
     dy_d = _t(_to_t32(dy), dev)
     slab = torch.zeros((5, K * N + N), device=dev)
-    check(lib().mava_rec_xty_f32(_cp(), ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), 0, K, N, rows, 1, 1.0,
+    check(lib().mava_rec_xty_f32(_cp(), ptr(obs_d), 1, ptr(idx_d), Rm, E, A, 1, K, ptr(dy_d), 0, None, 0, 0, K, N, rows, 1, 1.0,
                                  ptr(slab), slab.shape[1], 5, stream_ptr()), "xty")
     out = torch.zeros(K * N + N, device=dev)
     ops.slab_reduce(slab, K * N + N, out)
@@ -115,13 +115,24 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, rec_mode):
     dy2 = rng.standard_normal((rows, 384)).astype(np.float32)
     x2_d, dy2_d = _t(_to_t32(x2), dev), _t(_to_t32(dy2), dev)
     slab = torch.zeros((3, 128 * 384 + 384), device=dev)
-    check(lib().mava_rec_xty_f32(_cp(), ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 0, 128, 384, rows, 1, 0.25,
+    check(lib().mava_rec_xty_f32(_cp(), ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(dy2_d), 0, None, 0, 0, 128, 384, rows, 1, 0.25,
                                  ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32")
     out = torch.zeros(128 * 384 + 384, device=dev)
     ops.slab_reduce(slab, out.numel(), out)
     assert_close(out.cpu().numpy()[: 128 * 384].reshape(128, 384), 0.25 * x2.astype(np.float64).T @ dy2.astype(np.float64), 1e-5,
                  "xty t32 (out_scale 0.25)")
     assert_close(out.cpu().numpy()[128 * 384 :], 0.25 * dy2.astype(np.float64).sum(0), 1e-5, "xty t32 db")
+    # Y in two pieces (y_tail): features [0, 256) from a 384-wide matrix whose last third holds something else, [256, 384) from
+    # a 128-wide one - how the BPTT scan leaves dgh (its r and z thirds are dgi's)
+    head = dy2.copy()
+    head[:, 256:] = 99.0
+    head_d, tail_d = _t(_to_t32(head), dev), _t(_to_t32(np.ascontiguousarray(dy2[:, 256:])), dev)
+    slab = torch.zeros((3, 128 * 384 + 384), device=dev)
+    check(lib().mava_rec_xty_f32(_cp(), ptr(x2_d), 0, None, 0, 0, 0, 1, 128, ptr(head_d), 0, ptr(tail_d), 256, 128, 128, 384, rows, 1, 0.25,
+                                 ptr(slab), slab.shape[1], 3, stream_ptr()), "xty t32, y_tail")
+    out2 = torch.zeros(128 * 384 + 384, device=dev)
+    ops.slab_reduce(slab, out2.numel(), out2)
+    assert torch.equal(out2, out), "X^T Y with Y in two pieces == the same product on the whole matrix, bit for bit"
     # the gathered observations as a padded T32 matrix (mava_rec_gather_t32_f32), then both products on T32 operands:
     # the path the f16x2 arithmetic takes (exact copies in either mode)
     for src_d, share, xs in ((obs_d, 1, xg), (gs_d, A, np.repeat(gs[:, idx], A, 1).reshape(rows, K).astype(np.float64))):
@@ -136,7 +147,7 @@ def test_rec_dense_rowmajor_gather_and_xty(dev, rec_mode):
             assert_close(_from_t32(y.cpu().numpy(), rows, N), np.maximum(xs @ w.astype(np.float64) + b, 0), 1e-5,
                          "dense, gathered T32")
         slab = torch.zeros((5, K * N + N), device=dev)
-        check(lib().mava_rec_xty_f32(_cp(), ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
+        check(lib().mava_rec_xty_f32(_cp(), ptr(xin), 0, None, 0, 0, 0, 1, kp, ptr(dy_d), 0, None, 0, 0, K, N, rows, 1, 1.0, ptr(slab), slab.shape[1], 5,
                                      stream_ptr()), "xty on the gathered input")
         out = torch.zeros(K * N + N, device=dev)
         ops.slab_reduce(slab, K * N + N, out)

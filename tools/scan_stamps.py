@@ -35,7 +35,7 @@ for Rm, A in ((8192, 8), (1024, 1)):
     wh = torch.randn(128 * 384, device=dev) * 0.1
     idx = torch.randperm(E, device=dev)[: Rm // A].to(torch.int32).contiguous()
     done = (torch.rand((T, E, A), device=dev) < 0.02).to(torch.uint8)
-    run = lambda: check(L.mava_gru_scan_bwd_f32(CTX.handle, T, Rm, E, A, ptr(idx), ptr(done), ptr(wh), ptr(saved), ptr(hprev), ptr(dh), ptr(dgi), ptr(dgh), stream_ptr()), "scanb")
+    run = lambda: check(L.mava_gru_scan_bwd_f32(CTX.handle, T, Rm, E, A, ptr(idx), ptr(done), ptr(wh), ptr(saved), ptr(hprev), ptr(dh), ptr(dgi), ptr(dgh), 0, stream_ptr()), "scanb")
     for _ in range(2): run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -95,9 +95,9 @@ class RecLearner:
         action_head = make_action_head(config.network.get("action_head", None), env.action_dim)
         self.continuous = type(action_head).__name__ == "ContinuousActionHead"
         self.min_scale = float(getattr(action_head, "min_scale", 1e-3))
-        if self.continuous and not getattr(action_head, "independent_std", True):
-            raise NotImplementedError("ContinuousActionHead(independent_std=False) is built for the feed-forward systems "
-                                      "(general network path), not for the recurrent ones")
+        # ContinuousActionHead(independent_std=False): the log_std layer is a second head of the actor's post-torso, which then
+        # runs on the general layer kernels (mava_amd/generic_networks.py) whatever its torsos are
+        self.dep_std = self.continuous and not getattr(action_head, "independent_std", True)
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
             self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
@@ -129,7 +129,7 @@ class RecLearner:
         net = config.network
         from .generic_networks import CNNTorso, GenericMLPTorso
 
-        def torsos(nc):
+        def torsos(nc, general=False):
             """(pre, post) of one network: network/rnn.yaml's [128] relu torsos run on the dedicated kernels; any other
             configuration - MLPTorso layer sizes / tanh / layer norm, or network/rcnn.yaml's CNNTorso pre-torso - makes BOTH
             torsos of that network general ones."""
@@ -139,15 +139,15 @@ class RecLearner:
                 raise ValueError("post_torso cannot be a CNNTorso: it consumes the hidden features (network/rcnn.yaml uses an MLPTorso)")
             if is_cnn(nc.pre_torso):
                 return CNNTorso(**cfgs[0]), GenericMLPTorso(**cfgs[1])
-            default = all(list(c.get("layer_sizes", [128])) == [128] and c.get("activation", "relu") == "relu"
-                          and not c.get("use_layer_norm", False) for c in cfgs)
+            default = not general and all(list(c.get("layer_sizes", [128])) == [128] and c.get("activation", "relu") == "relu"
+                                          and not c.get("use_layer_norm", False) for c in cfgs)
             return tuple((MLPTorso if default else GenericMLPTorso)(**c) for c in cfgs)
 
         hsd = int(net.get("hidden_state_dim", 128))
         env0 = self.reps[0].env
         obs_shape = getattr(env0, "obs_shape", None)  # (H, W, C) observations for CNN pre-torsos (env.synthetic.obs_shape)
         state_shape = getattr(env0, "state_shape", None) if centralised_critic else obs_shape
-        self.actor_network = RecurrentActor(*torsos(net.actor_network), action_head, self.Oa, hsd, obs_shape)
+        self.actor_network = RecurrentActor(*torsos(net.actor_network, general=self.dep_std), action_head, self.Oa, hsd, obs_shape)
         self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd, state_shape)
         self.actor_network.ctx = self.critic_network.ctx = self.ctx
         self.generic_nets = self.actor_network.generic or self.critic_network.generic
@@ -304,8 +304,9 @@ class RecLearner:
                                                     A, training=False)
                 rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
                 if self.continuous:
-                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, self.min_scale, ptr(ws.y), ptr(self.actor_network.log_std(pa)), None,
-                                                               self.seed & (2**64 - 1), step & 0xFFFFFFFF,
+                    ind = not self.dep_std
+                    check(lib().mava_seq_sample_continuous_f32(EA, self.nA, self.min_scale, ptr(ws.y), ptr(self.actor_network.log_std(pa)) if ind else None,
+                                                               None if ind else ptr(ws.y2), self.seed & (2**64 - 1), step & 0xFFFFFFFF,
                                                                ((self.rank * self.U + u) * EA) & 0xFFFFFFFF, 0, ptr(rep.action[t]),
                                                                ptr(rep.log_prob[t]), stream_ptr()), "mava_seq_sample_continuous_f32")
                 else:
@@ -385,12 +386,16 @@ class RecLearner:
                                                          self.g[: self.Pa], self.g[self.P : self.P + 2], acc, self.grad_scale)
                     assert ok, "mava_rec_out_f32 refused a shape RecLearner.fused_out admitted"
                 elif self.continuous:
+                    ind = not self.dep_std
                     check(L.mava_seq_actor_loss_continuous_f32(
-                        T, Rm, E, A, self.nA, self.min_scale, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)), None, ptr(rep.action),
+                        T, Rm, E, A, self.nA, self.min_scale, ptr(idx), ptr(ws.y), ptr(self.actor_network.log_std(pa)) if ind else None,
+                        None if ind else ptr(ws.y2), ptr(rep.action),
                         ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0], float(s.clip_eps), float(s.ent_coef),
                         self.seed & (2**64 - 1), self.ent_step & 0xFFFFFFFF, ((self.rank * self.U + u) * T * E * A) & 0xFFFFFFFF,
-                        self.grad_scale, ptr(ws.dy), None, ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st), "mava_seq_actor_loss_continuous_f32")
-                    ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
+                        self.grad_scale, ptr(ws.dy), None if ind else ptr(ws.dy2), ptr(ws.loss_partials), ptr(self.dscale_partials), nblk, st),
+                          "mava_seq_actor_loss_continuous_f32")
+                    if ind:
+                        ops.slab_reduce(self.dscale_partials, self.nA, self.actor_network.log_std(self.g[: self.Pa]), accumulate=acc)
                 else:
                     check(L.mava_seq_actor_loss_f32(T, Rm, E, A, self.nA, ptr(idx), ptr(ws.y), ptr(rep.action_mask[:T]), ptr(rep.action),
                                                     ptr(rep.log_prob), ptr(rep.adv), ptr(self.stats), self.stats.shape[0],

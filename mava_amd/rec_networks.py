@@ -51,6 +51,15 @@ class RecWorkspace:
             self.hprev, self.saved = f(H), f(4 * H)
             self.dy, self.dpost, self.dh_out, self.dgi, self.dgh, self.dxpre = f(n_out_max), f(H), f(H), f(G3), f(H), f(H)  # (dgh: n third)
             self.loss_partials = torch.zeros((1024, 2), device=device)  # one partial per loss-kernel block (4 blocks per CU)
+        self.y2 = self.dy2 = None  # second head (ContinuousActionHead(independent_std=False): the log_std layer), on first use
+        self._n_out_max = n_out_max
+
+    def second_head(self, training: bool):
+        if self.y2 is None:
+            self.y2 = torch.empty(self.rows * self._n_out_max, device=self.hs.device)
+        if training and self.dy2 is None:
+            self.dy2 = torch.empty(self.rows * self._n_out_max, device=self.hs.device)
+        return self.y2, self.dy2
 
 
 class _RecurrentNet:
@@ -68,7 +77,8 @@ class _RecurrentNet:
             self.pre.ctx = value
             self.post.ctx = value
 
-    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None, obs_shape=None):
+    def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None, obs_shape=None,
+                 heads=None):
         if hidden_state_dim != H:
             raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
         self.din, self.n_out = int(din), int(n_out)
@@ -83,7 +93,8 @@ class _RecurrentNet:
                 raise ValueError("post_torso consumes the 128 hidden features: it cannot be a CNNTorso (network/rcnn.yaml: MLPTorso)")
             # network/rcnn.yaml: CNNTorso pre-torso on (H, W, C) observations (im2col + the same products, section 3.11)
             self.pre = GenericNet(pre_torso, self.din, [], obs_shape=obs_shape if isinstance(pre_torso, CNNTorso) else None)
-            self.post = GenericNet(post_torso, H, [("head", self.n_out, self.head_scale)])
+            # heads of the post-torso: one Dense(n_out), or ContinuousActionHead(independent_std=False)'s mean and log_std layers
+            self.post = GenericNet(post_torso, H, heads or [("head", self.n_out, self.head_scale)])
             Np, off = self.pre.feat, self.pre.num_params
             segs = []
             for name, shape in (("Wi", (Np, G3)), ("bi", (G3,)), ("Wh", (H, G3)), ("bhn", (H,))):
@@ -93,6 +104,8 @@ class _RecurrentNet:
             self.segments, self.num_params = segs, off + self.post.num_params
             self.Np = Np
         else:
+            if heads is not None and len(heads) > 1:
+                raise ValueError("several heads run on the general torsos (GenericMLPTorso)")
             self.segments, self.num_params = rec_segments(self.din, self.n_out)
         self.num_net_params = self.num_params  # the continuous actor appends log_std(n_out) behind the network
         self.off = {n: (o, s) for n, s, o in self.segments}
@@ -208,12 +221,15 @@ class _RecurrentNet:
         fpost = flat[self.post_off : self.post_off + self.post.num_params]
         self.post.load_torso_tree(p["post_torso"], fpost)
         self.post.load_head_leaf(head, 0, fpost)
+        dep_std = "action_head" in p and isinstance(p["action_head"].get("log_std", None), dict)  # a Dense layer's {kernel, bias}
+        if dep_std:
+            self.post.load_head_leaf(p["action_head"]["log_std"], 1, fpost)
         for g, (ik, hk) in enumerate((("ir", "hr"), ("iz", "hz"), ("in", "hn"))):
             self.seg(flat, "Wi")[:, g * H : (g + 1) * H].copy_(leaf(cell[ik]["kernel"], (self.Np, H)))
             self.seg(flat, "bi")[g * H : (g + 1) * H].copy_(leaf(cell[ik]["bias"], (H,)))
             self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(leaf(cell[hk]["kernel"], (H, H)))
         self.seg(flat, "bhn").copy_(leaf(cell["hn"]["bias"], (H,)))
-        if "action_head" in p and "log_std" in p["action_head"]:
+        if "action_head" in p and "log_std" in p["action_head"] and not dep_std:
             flat[self.num_net_params : self.num_net_params + self.n_out].copy_(leaf(p["action_head"]["log_std"], (self.n_out,)))
         return flat
 
@@ -248,6 +264,8 @@ class _RecurrentNet:
         # the padded batch is presented as Rp single-agent "envs", identity permutation
         y = self.forward_sequence(flat, ws, xp, 1, dp, hp, False, None, T, Rp, Rp, 1, training=False)
         out = t32_to_rows(y, self.n_out, T * Rp).view(T, Rp, self.n_out)[:, :R].reshape(T, E, A, self.n_out)
+        self._applied_second = (t32_to_rows(ws.y2, self.n_out, T * Rp).view(T, Rp, self.n_out)[:, :R].reshape(T, E, A, self.n_out)
+                                if ws.y2 is not None else None)
         h_last = t32_to_rows(ws.hs[(T - 1) * Rp * H : T * Rp * H], H, Rp)[:R].reshape(E, A, H)
         return h_last, out
 
@@ -270,10 +288,13 @@ class _RecurrentNet:
                    ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
             if stop_after_scan:
                 raise NotImplementedError("the fused output path serves the default torsos only")
-            y = self.post.forward(flat[self.post_off : self.post_off + self.post.num_params], wpost, None, 1, None, rows, rows, 1,
-                                  x_t32=ws.hs)[0]
+            outs = self.post.forward(flat[self.post_off : self.post_off + self.post.num_params], wpost, None, 1, None, rows, rows, 1,
+                                     x_t32=ws.hs)
+            y = outs[0]
             dst = ws.y if y_out is None else y_out  # (the losses / sampling kernels read the workspace's output buffer)
             dst.view(-1)[: y.numel()].copy_(y)
+            if len(outs) > 1:  # the log_std layer's rows (networks.py:161)
+                ws.second_head(training)[0][: outs[1].numel()].copy_(outs[1])
             return dst
         # pre-torso: inputs wider than 384 are consumed in column blocks (accumulating products; the weight
         # slice of one block stays register-resident), the ReLU rides on the last block
@@ -337,7 +358,8 @@ class _RecurrentNet:
             wpre, wpost, dfeat = self._gen_ws(ws, True)
             fpost = flat[self.post_off : self.post_off + self.post.num_params]
             gpost = grad_out[self.post_off : self.post_off + self.post.num_params]
-            self.post.backward(fpost, wpost, [ws.dy], gpost, accumulate, grad_scale, dx_out=ws.dh_out)
+            self.post.backward(fpost, wpost, [ws.dy] + ([ws.dy2] if len(self.post.heads) > 1 else []), gpost, accumulate, grad_scale,
+                               dx_out=ws.dh_out)
             launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
                    ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), 1, s)  # (dgh: the n third alone)
             o = lambda n: self.off[n][0]
@@ -409,10 +431,14 @@ class RecurrentActor(_RecurrentNet):
 
     def __init__(self, pre_torso: MLPTorso, post_torso: MLPTorso, action_head, obs_dim: int,
                  hidden_state_dim: int = 128, obs_shape=None):
-        super().__init__(obs_dim, action_head.action_dim, hidden_state_dim, pre_torso, post_torso, obs_shape)
         self.continuous = isinstance(action_head, ContinuousActionHead)
+        # networks.py:137-141: log_std is a parameter vector, or (independent_std=False) a second Dense layer on the embedding
+        self.independent_std = bool(getattr(action_head, "independent_std", True)) or not self.continuous
+        n = int(action_head.action_dim)
+        heads = None if self.independent_std else [("mean", n, self.head_scale), ("log_std", n, self.head_scale)]
+        super().__init__(obs_dim, n, hidden_state_dim, pre_torso, post_torso, obs_shape, heads=heads)
         self.action_head = action_head
-        if self.continuous:
+        if self.continuous and self.independent_std:
             self.num_params += self.n_out
 
     def log_std(self, flat: torch.Tensor) -> torch.Tensor:
@@ -420,9 +446,12 @@ class RecurrentActor(_RecurrentNet):
 
     def tree(self, flat: torch.Tensor, lead: Tuple[int, ...] = ()) -> Dict[str, Any]:
         out = super().tree(flat, lead)
-        if self.continuous:
+        if self.continuous and self.independent_std:
             ls = self.log_std(flat)
             out["params"]["action_head"]["log_std"] = ls.expand(*lead, self.n_out) if lead else ls
+        elif self.continuous:
+            fpost = flat[self.post_off : self.post_off + self.post.num_params]
+            out["params"]["action_head"]["log_std"] = self.post.head_leaf(fpost, 1, lead)
         return out
 
     def _head_tree(self, head):
@@ -437,7 +466,8 @@ class RecurrentActor(_RecurrentNet):
         flat = params if isinstance(params, torch.Tensor) else self.flat_from_tree(params)
         h, logits = self._apply_sequence(flat, hstate, observation.agents_view, done)
         if self.continuous:
-            return h, TanhNormal(logits, self.log_std(flat.float()), self.action_head.min_scale)
+            ls = self.log_std(flat.float()) if self.independent_std else self._applied_second
+            return h, TanhNormal(logits, ls, self.action_head.min_scale)
         return h, Categorical(logits, observation.action_mask)
 
 

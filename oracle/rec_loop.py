@@ -66,8 +66,10 @@ class OracleRecLearner:
             y, _, self.ha[u] = ro.rec_forward(self.pa[:n_net], self.Na, nA, av.reshape(1, E * A, -1), d_in[None], self.ha[u])
             if self.continuous:
                 eps = tn.normal_noise(self.seed, step, E * A, nA, tn.STREAM_SAMPLE, row_offset=u * E * A)
-                action = tn.sample(y[0], self.pa[n_net:], eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
-                lp = tn.log_prob(action, y[0], self.pa[n_net:])
+                two = isinstance(self.Na, dict) and self.Na.get("two_heads")  # ContinuousActionHead(independent_std=False)
+                mean, ls = (y[0][:, :nA], y[0][:, nA:]) if two else (y[0], self.pa[n_net:])
+                action = tn.sample(mean, ls, eps.astype(np.float64))[0].astype(np.float32).astype(np.float64)
+                lp = tn.log_prob(action, mean, ls)
                 action = action.reshape(E, A, nA)
             else:
                 z = po.masked_logits(y[0], mask.reshape(E * A, nA))

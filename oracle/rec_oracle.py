@@ -42,10 +42,17 @@ def rec_param_count(din, no: int) -> int:
 # ---- configurable pre / post torsos (mava/networks.py:39-58 MLPTorso inside RecurrentActor / RecurrentValueNet, :269-331):
 # wherever these functions take `din`, a dict from rec_spec() selects torsos other than network/rnn.yaml's [128] relu.
 # Flat layout = mava_amd/rec_networks.py's general layout: [pre torso layers | Wi | bi | Wh | bhn | post torso layers | head].
-def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False, pre_cnn=None):
+def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False, pre_cnn=None, two_heads=False):
     """pre_cnn = dict(shape=(H, W, C), channels, kernels, strides): a CNNTorso pre-torso (mava/networks.py:61-85, configs/network/
-    rcnn.yaml) instead of the MLP one; its flattened features feed the GRU."""
-    return dict(din=int(din), pre=list(pre_sizes or []), post=list(post_sizes), act=activation, ln=bool(layer_norm), pre_cnn=pre_cnn)
+    rcnn.yaml) instead of the MLP one; its flattened features feed the GRU.  two_heads: the post-torso carries TWO Dense(no)
+    heads - ContinuousActionHead(independent_std=False)'s mean and log_std layers (networks.py:137-141) - and the network's
+    output is their concatenation [mean | raw log_std] (2 no wide)."""
+    return dict(din=int(din), pre=list(pre_sizes or []), post=list(post_sizes), act=activation, ln=bool(layer_norm), pre_cnn=pre_cnn,
+                two_heads=bool(two_heads))
+
+
+def _heads(spec, no):
+    return [no, no] if spec.get("two_heads") else [no]
 
 
 def _pre_spec(spec):
@@ -73,7 +80,7 @@ def _spec_counts(spec, no):
     n_pre = go.param_count(_pre_spec(spec))
     np_ = _pre_width(spec)
     n_gru = np_ * 3 * H + 3 * H + H * 3 * H + H
-    n_post = go.param_count(go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"]))
+    n_post = go.param_count(go.spec_mlp(H, spec["post"], _heads(spec, no), spec["act"], spec["ln"]))
     return n_pre, n_gru, n_post, n_pre + n_gru + n_post
 
 
@@ -83,7 +90,7 @@ def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, d
     n_pre, n_gru, n_post, _ = _spec_counts(spec, no)
     np_ = _pre_width(spec)
     pre_spec = _pre_spec(spec)
-    post_spec = go.spec_mlp(H, spec["post"], [no], spec["act"], spec["ln"])
+    post_spec = go.spec_mlp(H, spec["post"], _heads(spec, no), spec["act"], spec["ln"])
     g = flat[n_pre : n_pre + n_gru]
     o = 0
     Wi = g[o : o + np_ * 3 * H].reshape(np_, 3 * H); o += np_ * 3 * H
@@ -102,7 +109,7 @@ def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, d
         z = torch.sigmoid(gi[:, H : 2 * H] + gh[:, H : 2 * H])
         n = torch.tanh(gi[:, 2 * H :] + r * (gh[:, 2 * H :] + bhn))
         h = (1.0 - z) * n + z * h
-        ys.append(go.forward(fpost, post_spec, h)[0])
+        ys.append(torch.cat(go.forward(fpost, post_spec, h), -1))  # (one head, or [mean | raw log_std])
     return torch.stack(ys), torch.stack(hs), h
 
 
@@ -235,9 +242,15 @@ def rec_actor_loss_grad_continuous(flat, din, dim, obs, done, h0, action, old_lo
 
     f = torch.tensor(np.asarray(flat, np.float64), requires_grad=True)
     tt = lambda a, dt=torch.float64: torch.tensor(np.asarray(a), dtype=dt)
+    from . import tanh_normal as tn
+
     n_net = rec_param_count(din, dim)
     mean, _ = t_rec_forward(f[:n_net], din, dim, tt(obs), tt(done, torch.bool), tt(h0))
-    scale = torch.nn.functional.softplus(f[n_net:]) + 1e-3
+    if isinstance(din, dict) and din.get("two_heads"):  # networks.py:161: scale from the log_std layer's rows
+        mean, raw = mean[..., :dim], mean[..., dim:]
+    else:
+        raw = f[n_net:]
+    scale = torch.nn.functional.softplus(raw) + tn.MIN_SCALE
     lp = t_tanh_normal_log_prob(tt(action), mean, scale)
     ratio = torch.exp(lp - tt(old_log_prob))
     g = tt(gae)

@@ -285,3 +285,86 @@ def test_continuous_rec_learner_update_matches_oracle(dev, monkeypatch, system, 
     init = {"hidden_state": torch.zeros((eval_env.num_envs, A, 128), device=dev)}
     m = ev(out.learner_state.params.actor_params, 0, init)
     assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes
+
+
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
+@pytest.mark.parametrize("system,U", [("rec_mappo", 1), ("rec_ippo", 2)])
+def test_rec_learner_state_dependent_std(dev, system, U, matmul):
+    """ContinuousActionHead(independent_std=False) on the RECURRENT systems (mava/networks.py:137-141,161 inside
+    RecurrentActor, :269-294): the log_std layer is a second head of the actor's post-torso (general layer kernels around the
+    GRU scans), whole updates against the oracle with the same two heads (rec_oracle.rec_spec(two_heads=True)), the
+    parameter tree with action_head/{mean, log_std}/{kernel, bias}, and the evaluator's distribution view."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_ippo, rec_mappo
+    from oracle import rec_oracle as ro
+    from oracle.rec_loop import OracleRecLearner
+
+    E, A, O, dim, T, K, M = 16, 4, 10, 3, 6, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}",
+                                        "network.action_head._target_=mava.networks.ContinuousActionHead"])
+    cfg.network.action_head.independent_std = False
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": dim}
+    cfg.env.kwargs.time_limit = 4
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    cfg.system.matmul_mode = matmul
+    central = system == "rec_mappo"
+    mod = rec_mappo if central else rec_ippo
+    env, eval_env = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    assert L.continuous and L.dep_std and L.actor_network.generic and not L.critic_network.generic
+    head = state.params.actor_params["params"]["action_head"]
+    assert head["mean"]["kernel"].shape == (1, U, 128, dim) and head["log_std"]["kernel"].shape == (1, U, 128, dim)
+    assert head["log_std"]["bias"].shape == (1, U, dim)
+    assert torch.equal(actor_network.flat_from_tree(state.params.actor_params), L.p[: L.Pa])
+    Oc = A * O if central else A + O
+    spec_a = ro.rec_spec(A + O, [128], [128], "relu", False, two_heads=True)
+    assert L.Pa == ro.rec_param_count(spec_a, dim) and L.Pc == ro.rec_param_count(Oc, 1)
+
+    rng = np.random.default_rng(3)
+    fa = (rng.standard_normal(L.Pa) * 0.1).astype(np.float32)
+    fc = ro.init_rec(rng, Oc, 1, 1.0).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleRecLearner(E=E, A=A, O=O, nA=dim, T=T, K=K, M=M, U=U, centralised=central, seed=42, actor_lr=1e-3,
+                           critic_lr=2e-3, time_limit=4, continuous=True, actor_net=spec_a)
+    ora.set_params(fa, fc)
+    ftol = 1e-5 if matmul == "f32" else 5e-5
+    for n in range(2):
+        perms = [rng.permutation(E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[u]
+            assert_close(rep.action.cpu().numpy(), tr["action"], 5e-5 if matmul == "f16x2" else 1e-5, "actions", scale=1.0)
+            assert tr["done_in"].any()
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], 1e-4, "log_probs", scale=1.0)
+            assert_close(rep.value.cpu().numpy(), tr["value"], ftol, "values")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], ftol, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        if matmul == "f32":
+            assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+            assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        else:
+            check_and_sync_f16x2_state(L, ora)
+    out = learn(L.learner_state())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()
+    # evaluator seam: the distribution's scale comes from the log_std layer's rows
+    from mava_amd.evaluator import get_eval_fn, make_rec_eval_act_fn
+    from mava_amd.types import Observation
+
+    rep = L.reps[0]
+    obs = Observation(rep.agents_view[:1], None, None)
+    _, pi = actor_network.apply(out.learner_state.params.actor_params, torch.zeros((E, A, 128), device=dev),
+                                (obs, torch.zeros((1, E, A), dtype=torch.bool, device=dev)))
+    assert pi.scale.shape == pi.loc.shape == (1, E, A, dim) and (pi.scale > 0).all() and pi.scale.std() > 0
+    h0 = torch.zeros((eval_env.num_envs, A, 128), device=dev)
+    ev = get_eval_fn(eval_env, make_rec_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
+    m = ev(out.learner_state.params.actor_params, 0, {"hidden_state": h0})
+    assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes

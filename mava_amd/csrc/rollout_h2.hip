@@ -648,14 +648,17 @@ int launch_rollout(const RolloutArgs& a, hipStream_t s) {
   g_rollout_last_instance = NO * 100000 + S1A * 1000 + S1C * 10 + (SHARED ? 1 : 0);
   const RolloutLds L = make_rollout_lds<NO, S1A, S1C, SHARED>();
   MAVA_ARG_CHECK(L.end <= 163840, 8, "mava_rollout_ff_f32: %d bytes of LDS exceed the 160 KiB of a CU", L.end);
+  // (more than half a CU's LDS whatever the layout needs - the benchmarked layouts take ~150 KB anyway: two rollouts launched
+  // side by side, the replicas of update_batch_size > 1, are never placed on one CU while others idle)
+  const int lds_bytes = L.end > 83968 ? L.end : 83968;
   static bool attr_set = false;
   if (!attr_set) {
     MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)rollout_h2_kernel<NO, S1A, S1C, SHARED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.end));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   const int EB = 64 / a.A;
-  hipLaunchKernelGGL((rollout_h2_kernel<NO, S1A, S1C, SHARED>), dim3(mava_cdiv(a.E, EB)), dim3(512), L.end, s, a, L);
+  hipLaunchKernelGGL((rollout_h2_kernel<NO, S1A, S1C, SHARED>), dim3(mava_cdiv(a.E, EB)), dim3(512), lds_bytes, s, a, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

@@ -24,6 +24,7 @@ gradient is summed with one all-reduce per minibatch (ff_mappo.py:224-238 pmean 
 from __future__ import annotations
 
 import math
+import contextlib
 import os
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -204,11 +205,15 @@ class FFLearner:
                               and int(getattr(env0, "synth_state_dim", 0)) == 0
                               and (not centralised_critic or (env0.gs_tiles == 1 and env0.global_state_shared)))
         self._learn_calls = 0  # guards.check_f16_range: the previous call's metrics are checked from the second call on
-        # One rank, one replica: nothing sits between the gradient kernels and Adam, so both slab sums, clip + Adam, the
-        # count increment and the wide critic's W1 re-split run as TWO launches (ops.ppo_finish) instead of six
-        self.fused_tail = (self.U == 1 and self.world == 1 and not self.generic
-                           and os.environ.get("MAVA_FUSED_TAIL", "1") != "0")
+        # One rank: nothing sits between the gradient kernels and Adam, so both slab sums, clip + Adam, the count increment and
+        # the wide critic's W1 re-split run as TWO launches (ops.ppo_finish) instead of six.  With several replicas every
+        # replica's gradient kernels write their own rows of the slab matrices and the one sum runs over all U * n_slab rows
+        # (fixed order: replica 0's slabs, then replica 1's, ...; the mean over replicas of ff_mappo.py:232-238 is grad_scale).
+        self.fused_tail = (self.world == 1 and not self.generic and os.environ.get("MAVA_FUSED_TAIL", "1") != "0")
         self._finish_ws = ops.ppo_finish_workspace(self.Pa, self.Pc, d) if self.fused_tail else None
+        if self.fused_tail and self.U > 1:
+            self.slab_a = torch.zeros((self.U * self.n_slab, self.Pa + 2), device=d)
+            self.slab_c = torch.zeros((self.U * self.n_slab, self.Pc + 2), device=d)
 
     def _timed(self, name: str, fn, *args, **kwargs):
         """Run one kernel launch, optionally bracketed by HIP events on the launch stream."""
@@ -336,9 +341,19 @@ class FFLearner:
         s = self.config.system
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         EA = self.E * self.A
+        # The replicas' rollouts are independent (ff_mappo.py:389 vmaps over update_batch_size) and one replica of the reference's
+        # default shape (2 x 2048 envs) fills half the CUs: replicas 1.. are launched on side streams, under replica 0's.
+        main = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        side = self.U > 1 and self.timers is None and main is not None and os.environ.get("MAVA_ROLLOUT_STREAMS", "1") != "0"
+        if side and not hasattr(self, "_roll_streams"):
+            self._roll_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.U - 1)]
+        if side:
+            for st in self._roll_streams:  # (before replica 0's launch is queued: the side streams wait for the parameters only)
+                st.wait_stream(main)
         for u, rep in enumerate(self.reps):
             env = rep.env
-            ok = self._timed(
+            with (torch.cuda.stream(self._roll_streams[u - 1]) if (side and u > 0) else contextlib.nullcontext()):
+              ok = self._timed(
                 "rollout_fused", ops.rollout_ff, pa, pc, n_actions=self.nA, critic_shared=self.centralised, E=self.E,
                 A=self.A, O=env.raw_obs_dim, T=self.T, time_limit=env.time_limit, policy_seed=self.seed,
                 env_seed=env.seed, t0=self.t_global, row_offset=(self.rank * self.U + u) * EA, env_offset=env.env_offset,
@@ -348,12 +363,15 @@ class FFLearner:
                 last_val=rep.last_val, info_return=rep.info_return[n], info_length=rep.info_length[n],
                 info_terminal=rep.info_terminal[n], adv=rep.adv, tgt=rep.tgt, gamma=float(s.gamma),
                 gae_lambda=float(s.gae_lambda))
-            if not ok:
+              if not ok:
                 assert u == 0
                 self.fused_rollout = False
                 return False
-            rep.last_reward.copy_(rep.reward[self.T - 1])
-            rep.last_done.copy_(rep.done[self.T - 1])
+              rep.last_reward.copy_(rep.reward[self.T - 1])
+              rep.last_done.copy_(rep.done[self.T - 1])
+        if side:
+            for st in self._roll_streams:
+                main.wait_stream(st)
         self.step_dev.add_(self.T)
         return True
 
@@ -423,7 +441,10 @@ class FFLearner:
             return self._minibatch_generic(n, k, mb, idx if idx is not None else torch.arange(base, base + self.Rb, dtype=torch.int32,
                                                                                              device=self.device))
         # actor: gradient kernels of every replica, fixed-order slab sum into g[:Pa] (+ actor_loss, entropy)
+        ns = self.n_slab
+        per_rep = self.fused_tail and self.U > 1  # (each replica's kernels own n_slab rows of the slab matrices)
         for u, rep in enumerate(self.reps):
+            slab_a = self.slab_a[u * ns : (u + 1) * ns] if per_rep else self.slab_a
             av = rep.agents_view[:T].view(TEA, self.Oa)
             if getattr(self, "_stats_batched", False) and perm is self._perm_bufs[k]:
                 stats = self._stats_all[u, k * self.M + mb]
@@ -433,11 +454,11 @@ class FFLearner:
                 self._timed("actor_grad", ops.ppo_actor_grad_continuous, pa, av, rep.action.view(TEA, self.nA),
                             rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base, self.Rb, A, self.nA,
                             float(s.clip_eps), float(s.ent_coef), self.seed, self.ent_step,
-                            (self.rank * self.U + u) * TEA, self.slab_a, min_scale=self.min_scale)
+                            (self.rank * self.U + u) * TEA, slab_a, min_scale=self.min_scale)
             else:
                 self._timed("actor_grad", ops.ppo_actor_grad, pa, av, rep.action_mask[:T].view(TEA, self.nA),
                             rep.action.view(TEA), rep.log_prob.view(TEA), rep.adv.view(TEA), stats, idx, base,
-                            self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), self.slab_a, ctx=self.ctx)
+                            self.Rb, A, self.nA, float(s.clip_eps), float(s.ent_coef), slab_a, ctx=self.ctx)
             if not self.fused_tail:
                 ops.slab_reduce2(self.slab_a, self.Pa, self.g[: self.Pa], 2, self.g[self.P : self.P + 2], accumulate=u > 0)
         # pmean "device" of ff_mappo.py:228-238, RCCL over xGMI: the actor's slice travels on RCCL's stream while
@@ -447,12 +468,13 @@ class FFLearner:
             av = rep.agents_view[:T].view(TEA, self.Oa)
             cx = rep.global_state[:T].view(-1, self.Oc) if self.centralised else av
             self._timed("critic_grad", ops.ppo_critic_grad, pc, cx, self.critic_share, rep.value.view(TEA), rep.tgt.view(TEA),
-                        idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef), self.slab_c, ctx=self.ctx)
+                        idx, base, self.Rb, A, float(s.clip_eps), float(s.vf_coef),
+                        self.slab_c[u * ns : (u + 1) * ns] if per_rep else self.slab_c, ctx=self.ctx)
             if not self.fused_tail:
                 ops.slab_reduce2(self.slab_c, self.Pc, self.g[self.Pa : self.P], 1, self.g[self.P + 2 : self.P + 3], accumulate=u > 0)
         if self.fused_tail:
             self._timed("finish", ops.ppo_finish, self.ctx, self.slab_a, self.slab_c, self.Pa, self.Pc, self.g, self.p, self.m, self.v,
-                        self.count, self.seg_lr[0], self.seg_lr[1], grad_scale=1.0, max_norm=float(s.max_grad_norm),
+                        self.count, self.seg_lr[0], self.seg_lr[1], grad_scale=1.0 / self.U, max_norm=float(s.max_grad_norm),
                         decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
                         num_updates=int(s.get("num_updates", 1) or 1), vf_coef=float(s.vf_coef), ent_coef=float(s.ent_coef),
                         metrics_out=self.train_metrics[n, k, mb], critic_din=self.Oc, workspace=self._finish_ws)

@@ -236,7 +236,7 @@ def _load_traffic(names):
 
 
 FF_TRAFFIC = ("r03_v3_pmc_traffic.json", "r03_v2_pmc_traffic.json", "r03_v1_pmc_traffic.json", "r02_v5_pmc_traffic.json")
-REC_TRAFFIC = ("r03_rec2_pmc_traffic.json", "r03_rec_pmc_traffic.json", "r02_rec3_pmc_traffic.json", "r02_rec2_pmc_traffic.json")
+REC_TRAFFIC = ("r03_rec2_pmc_traffic.json", "r03_rec1_pmc_traffic.json", "r02_rec3_pmc_traffic.json", "r02_rec2_pmc_traffic.json")
 
 
 def ff_rooflines(L, matmul: str, timers: dict, timer_steps: int, default_shape: bool, aggregated_off: bool, continuous: bool, dev,
@@ -356,7 +356,8 @@ def rec_rooflines(L, matmul: str, rec_timers: dict, timer_steps: int) -> dict:
     """Recurrent systems: the kernel with the most time per update is the roofline object.  The GRU scans
     are priced on BOTH rooflines - algorithmic FLOPs (h.W_h: 2*128*384 per row-step) and algorithmic HBM bytes per
     row-step (forward: read gi 1536 + done, write h 512 + saved gates 2048 + h_prev 512; BPTT: read saved 2048 + h_prev 512
-    + dh_out 512, write dgi 1536 + dgh 1536) - the binding one is `bound`."""
+    + dh_out 512, write dgi 1536 + the n third of dgh 512 - since round 3 the r and z thirds, equal to dgi's, are not
+    stored) - the binding one is `bound`."""
     out = {}
     T = L.T
     tms = {k: _ev_ms(v) for k, v in rec_timers.items()}
@@ -372,7 +373,7 @@ def rec_rooflines(L, matmul: str, rec_timers: dict, timer_steps: int) -> dict:
     dom, seqs = dom_key.split(":")[0], int(dom_key.split(":")[1])
     rows_avg = T * seqs                   # row-steps per launch
     flop = 2.0 * 128 * 384 * rows_avg
-    by = {"gru_scan_fwd": 1536 + 1 + 512 + 2048 + 512, "gru_scan_bwd": 2048 + 512 + 512 + 1536 + 1536}[dom] * rows_avg
+    by = {"gru_scan_fwd": 1536 + 1 + 512 + 2048 + 512, "gru_scan_bwd": 2048 + 512 + 512 + 1536 + 512}[dom] * rows_avg
     t_s = avg[dom_key] * 1e-3
     tf, gbs = flop / t_s / 1e12, by / t_s / 1e9
     # the matrix peak of the arithmetic the scan runs in: exact-f32 MFMAs, or three f16 MFMAs per product (f16x2)
@@ -382,7 +383,8 @@ def rec_rooflines(L, matmul: str, rec_timers: dict, timer_steps: int) -> dict:
     kname = f"{dom}_h2_kernel" if matmul == "f16x2" else f"{dom}_kernel"
     if seqs == 8192 and T == 128:
         tr, src = _load_traffic(REC_TRAFFIC)
-        rec_traffic = tr.get(f"{kname} grid={min(256, seqs // 32)}", {}).get("hbm_bytes_corrected")
+        grid = f" grid={min(256, seqs // 32)}"
+        rec_traffic = (tr.get(kname + grid) or tr.get(kname + "<true>" + grid) or {}).get("hbm_bytes_corrected")
         rec_src = src if rec_traffic else None
     if hbm_frac >= mfma_frac:
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

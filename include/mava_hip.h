@@ -405,6 +405,23 @@ int mava_t32_norm_act_f32(const float* x, int N, long rows, int use_layer_norm, 
 /* dz = dy * act'(y) (the bias gradient is its column sum); dx = gradient w.r.t. the layer-norm input (= dz without it) */
 int mava_t32_norm_act_bwd_f32(const float* dy, const float* y, int N, long rows, int use_layer_norm, const float* xhat,
                               const float* rstd, int act, float* dz, float* dx, mava_stream_t s);
+/* GRU cell one time step at a time, for network.hidden_state_dim != 128 (mava/networks.py:222-266: ScannedRNN over flax
+ * GRUCell; the register-resident scans mava_gru_scan_* serve 128).  All matrices T32 over the `rows` sequences of the step;
+ * done_t / done_next: the external (E, A) u8 flags ENTERING that step, rows mapped through idx like the scans; the
+ * recurrent products (h W_h, dgh W_h^T) are mava_rec_dense_f32 launches between these kernels.
+ *   mask:      hprev = done_t ? 0 : h
+ *   gates:     hs = GRUCell(gi, gh = hprev W_h, b_hn, hprev); saved (rows x 4 Hd) = [r | z | n | gh_n + b_hn] or NULL;
+ *              hprev_next (or NULL) = done_next ? 0 : hs
+ *   gates_bwd: dh = dh_out + (done_next ? 0 : acc_next + dhp_next) (acc_next = dgh_{t+1} W_h^T; NULL at the last step);
+ *              dgi, dgh (rows x 3 Hd) and dhp = dh z */
+int mava_t32_gru_mask_f32(const float* h, const uint8_t* done_t, const int32_t* idx, int E, int A, int Hd, long rows,
+                          float* hprev, mava_stream_t s);
+int mava_t32_gru_gates_f32(const float* gi, const float* gh, const float* bhn, const float* hprev, int Hd, long rows, float* hs,
+                           float* saved, float* hprev_next, const uint8_t* done_next, const int32_t* idx, int E, int A,
+                           mava_stream_t s);
+int mava_t32_gru_gates_bwd_f32(const float* saved, const float* hprev, const float* dh_out, const float* acc_next,
+                               const float* dhp_next, const uint8_t* done_next, const int32_t* idx, int E, int A, int Hd,
+                               long rows, float* dgi, float* dgh, float* dhp, mava_stream_t s);
 /* per-block partial column sums of a T32 matrix times `scale`: slab (n_slab, slab_stride >= N) */
 int mava_t32_colsum_f32(const float* y, int N, long rows, float scale, float* slab, long slab_stride, int n_slab,
                         mava_stream_t s);

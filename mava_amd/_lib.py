@@ -66,6 +66,9 @@ _SIGNATURES = {
     "mava_rec_xty_f32": [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp, lng, i32, vp],
     "mava_rec_gather_t32_f32": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mava_gru_scan_fwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "mava_t32_gru_mask_f32": [vp, vp, vp, i32, i32, i32, lng, vp, vp],
+    "mava_t32_gru_gates_f32": [vp, vp, vp, vp, i32, lng, vp, vp, vp, vp, vp, i32, i32, vp],
+    "mava_t32_gru_gates_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, lng, vp, vp, vp, vp],
     "mava_gru_scan_bwd_f32": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "mava_seq_actor_loss_f32": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, i32, vp],
     "mava_rec_step_continuous_f32": [vp, i32, i32, f32, vp, vp, vp, vp, i32, u64, u32, u32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp],

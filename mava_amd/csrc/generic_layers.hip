@@ -204,6 +204,94 @@ int blocks_for(long total) {
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
+
+// ---- GRU cell, one time step at a time, for hidden widths the register-resident scans (rec_gru.hip: 128) do not serve:
+// network.hidden_state_dim != 128 (mava/networks.py:222-266 ScannedRNN over flax GRUCell).  The recurrent product h W_h is a
+// T32 dense launch per step (rec_dense.hip); these kernels are what sits around it.  A lane owns a row (sequence) of the
+// step; feature f of the step's T32 matrices at ((row / 32) * N + f) * 32 + row % 32.
+__device__ __forceinline__ bool step_done(const uint8_t* done_t, const int32_t* idx, int E, int A, long row) {
+  const long e_local = row / A, a = row - e_local * A;
+  const long env = idx ? idx[e_local] : e_local;
+  (void)E;
+  return done_t[env * A + a] != 0;
+}
+
+// hprev = done ? 0 : h   (networks.py:253-257: the flag entering the step resets the carried state)
+__global__ __launch_bounds__(256) void gru_mask_kernel(const float* __restrict__ h, const uint8_t* __restrict__ done_t,
+                                                       const int32_t* __restrict__ idx, int E, int A, int Hd, long rows,
+                                                       float* __restrict__ hprev) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const bool d = step_done(done_t, idx, E, A, row);
+  const long base = (row >> 5) * Hd * 32 + (row & 31);
+  for (int f = 0; f < Hd; ++f) hprev[base + (long)f * 32] = d ? 0.0f : h[base + (long)f * 32];
+}
+
+// flax GRUCell: r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r (gh_n + b_hn)), h' = (1 - z) n + z h.
+// saved = [r | z | n | gh_n + b_hn]; hprev_next (optional) = the state entering the next step, masked by its done flag.
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                        const float* __restrict__ bhn, const float* __restrict__ hprev, int Hd,
+                                                        long rows, float* __restrict__ hs, float* __restrict__ saved,
+                                                        float* __restrict__ hprev_next, const uint8_t* __restrict__ done_next,
+                                                        const int32_t* __restrict__ idx, int E, int A) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const long t3 = (row >> 5) * (3L * Hd) * 32 + (row & 31), t1 = (row >> 5) * (long)Hd * 32 + (row & 31);
+  const long t4 = (row >> 5) * (4L * Hd) * 32 + (row & 31);
+  const bool dn = (hprev_next != nullptr) && step_done(done_next, idx, E, A, row);
+  for (int f = 0; f < Hd; ++f) {
+    const float r = 1.0f / (1.0f + expf(-(gi[t3 + (long)f * 32] + gh[t3 + (long)f * 32])));
+    const float z = 1.0f / (1.0f + expf(-(gi[t3 + (long)(Hd + f) * 32] + gh[t3 + (long)(Hd + f) * 32])));
+    const float hl = gh[t3 + (long)(2 * Hd + f) * 32] + bhn[f];
+    const float n = tanhf(gi[t3 + (long)(2 * Hd + f) * 32] + r * hl);
+    const float hp = hprev[t1 + (long)f * 32];
+    const float hn = (1.0f - z) * n + z * hp;
+    hs[t1 + (long)f * 32] = hn;
+    if (saved != nullptr) {
+      saved[t4 + (long)f * 32] = r;
+      saved[t4 + (long)(Hd + f) * 32] = z;
+      saved[t4 + (long)(2 * Hd + f) * 32] = n;
+      saved[t4 + (long)(3 * Hd + f) * 32] = hl;
+    }
+    if (hprev_next != nullptr) hprev_next[t1 + (long)f * 32] = dn ? 0.0f : hn;
+  }
+}
+
+// One step of BPTT through the cell.  dh = dh_out + (the gradient carried from step t + 1: acc_next + dhp_next unless that
+// step's flag cut the chain); writes dgi (3 Hd), dgh (3 Hd: r and z thirds equal dgi's) and dhp = dh z (the direct path).
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ saved, const float* __restrict__ hprev,
+                                                            const float* __restrict__ dh_out, const float* __restrict__ acc_next,
+                                                            const float* __restrict__ dhp_next,
+                                                            const uint8_t* __restrict__ done_next, const int32_t* __restrict__ idx,
+                                                            int E, int A, int Hd, long rows, float* __restrict__ dgi,
+                                                            float* __restrict__ dgh, float* __restrict__ dhp) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const long t3 = (row >> 5) * (3L * Hd) * 32 + (row & 31), t1 = (row >> 5) * (long)Hd * 32 + (row & 31);
+  const long t4 = (row >> 5) * (4L * Hd) * 32 + (row & 31);
+  const bool carry = (acc_next != nullptr) && !step_done(done_next, idx, E, A, row);
+  for (int f = 0; f < Hd; ++f) {
+    const float rr = saved[t4 + (long)f * 32], zz = saved[t4 + (long)(Hd + f) * 32];
+    const float nn = saved[t4 + (long)(2 * Hd + f) * 32], hl = saved[t4 + (long)(3 * Hd + f) * 32];
+    const float hp = hprev[t1 + (long)f * 32];
+    const float dh = dh_out[t1 + (long)f * 32] + (carry ? (acc_next[t1 + (long)f * 32] + dhp_next[t1 + (long)f * 32]) : 0.0f);
+    const float dn = dh * (1.0f - zz);
+    const float dz = dh * (hp - nn);
+    const float dn_pre = dn * (1.0f - nn * nn);
+    const float dr = dn_pre * hl;
+    const float dghn = dn_pre * rr;
+    const float dz_pre = dz * zz * (1.0f - zz);
+    const float dr_pre = dr * rr * (1.0f - rr);
+    dgi[t3 + (long)f * 32] = dr_pre;
+    dgi[t3 + (long)(Hd + f) * 32] = dz_pre;
+    dgi[t3 + (long)(2 * Hd + f) * 32] = dn_pre;
+    dgh[t3 + (long)f * 32] = dr_pre;
+    dgh[t3 + (long)(Hd + f) * 32] = dz_pre;
+    dgh[t3 + (long)(2 * Hd + f) * 32] = dghn;
+    dhp[t1 + (long)f * 32] = dh * zz;
+  }
+}
+
 }  // namespace
 
 extern "C" int mava_t32_norm_act_f32(const float* x, int N, long rows, int use_layer_norm, const float* ln_bias, int act,
@@ -282,6 +370,42 @@ extern "C" int mava_t32_flatten_f32(const float* src, long samples, int P, int C
   if (samples == 0) return MAVA_OK;
   MAVA_ARG_CHECK(src && dst, 1, "mava_t32_flatten_f32: null pointer argument");
   hipLaunchKernelGGL(flatten_kernel, dim3(blocks_for(samples * P * C)), dim3(256), 0, s, src, samples, P, C, to_flat, dst);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_t32_gru_mask_f32(const float* h, const uint8_t* done_t, const int32_t* idx, int E, int A, int Hd, long rows,
+                                     float* hprev, hipStream_t s) {
+  MAVA_ARG_CHECK(Hd >= 1 && rows >= 0 && rows % 32 == 0 && E >= 1 && A >= 1, 0, "mava_t32_gru_mask_f32: Hd=%d rows=%ld", Hd, rows);
+  if (rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(h && done_t && hprev, 1, "mava_t32_gru_mask_f32: null pointer argument");
+  hipLaunchKernelGGL(gru_mask_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, h, done_t, idx, E, A, Hd, rows, hprev);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_t32_gru_gates_f32(const float* gi, const float* gh, const float* bhn, const float* hprev, int Hd, long rows,
+                                      float* hs, float* saved, float* hprev_next, const uint8_t* done_next, const int32_t* idx,
+                                      int E, int A, hipStream_t s) {
+  MAVA_ARG_CHECK(Hd >= 1 && rows >= 0 && rows % 32 == 0 && E >= 1 && A >= 1, 0, "mava_t32_gru_gates_f32: Hd=%d rows=%ld", Hd, rows);
+  if (rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(gi && gh && bhn && hprev && hs && (hprev_next == nullptr || done_next != nullptr), 1,
+                 "mava_t32_gru_gates_f32: null pointer argument");
+  hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, gi, gh, bhn, hprev, Hd, rows, hs, saved,
+                     hprev_next, done_next, idx, E, A);
+  MAVA_LAUNCH_CHECK();
+  return MAVA_OK;
+}
+
+extern "C" int mava_t32_gru_gates_bwd_f32(const float* saved, const float* hprev, const float* dh_out, const float* acc_next,
+                                          const float* dhp_next, const uint8_t* done_next, const int32_t* idx, int E, int A,
+                                          int Hd, long rows, float* dgi, float* dgh, float* dhp, hipStream_t s) {
+  MAVA_ARG_CHECK(Hd >= 1 && rows >= 0 && rows % 32 == 0 && E >= 1 && A >= 1, 0, "mava_t32_gru_gates_bwd_f32: Hd=%d rows=%ld", Hd, rows);
+  if (rows == 0) return MAVA_OK;
+  MAVA_ARG_CHECK(saved && hprev && dh_out && dgi && dgh && dhp && (acc_next == nullptr || (dhp_next && done_next)), 1,
+                 "mava_t32_gru_gates_bwd_f32: null pointer argument");
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, saved, hprev, dh_out, acc_next,
+                     dhp_next, done_next, idx, E, A, Hd, rows, dgi, dgh, dhp);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }

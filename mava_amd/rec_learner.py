@@ -34,8 +34,9 @@ from .types import (AdamState, ExperimentOutput, HiddenStates, Observation, Obse
 
 
 class _RecReplica(_Replica):
-    def __init__(self, env, T, n_upd, central, device, continuous: bool = False):
+    def __init__(self, env, T, n_upd, central, device, continuous: bool = False, hidden: int = H):
         super().__init__(env, T, n_upd, central, device, continuous)
+        self.Hd = int(hidden)  # network.hidden_state_dim
         E, A = env.num_envs, env.num_agents
         EA = E * A
         if EA % 32:
@@ -43,9 +44,9 @@ class _RecReplica(_Replica):
         self.dones = torch.zeros((E, A), dtype=torch.uint8, device=device)       # flag entering the next step
         self.done_in = torch.zeros((T, E, A), dtype=torch.uint8, device=device)  # transition.done = last_done (:136-137)
         # current hidden states in the kernels' T32 layout, and the rollout-initial copies (hstates[0], row-major)
-        self.h_actor = torch.zeros(EA * H, device=device)
+        self.h_actor = torch.zeros(EA * self.Hd, device=device)
         self.h_actor_next = torch.zeros_like(self.h_actor)
-        self.h0_actor = torch.zeros((E, A, H), device=device)
+        self.h0_actor = torch.zeros((E, A, self.Hd), device=device)
         self.set_critic_rows(A)
 
     def set_critic_rows(self, ac: int) -> None:
@@ -55,9 +56,9 @@ class _RecReplica(_Replica):
         self.Ac = ac
         # full E*A size even when only E rows are used: the buffer is swapped with the shared rollout workspace's
         # hidden-state output every step, which the actor fills with E*A rows
-        self.h_critic = torch.zeros(E * self.env.num_agents * H, device=dev)
+        self.h_critic = torch.zeros(E * self.env.num_agents * self.Hd, device=dev)
         self.h_critic_next = torch.zeros_like(self.h_critic)  # ping-pong partner for the fused acting step
-        self.h0_critic = torch.zeros((E, ac, H), device=dev)
+        self.h0_critic = torch.zeros((E, ac, self.Hd), device=dev)
         # per-env copies of the entering done flags and a value scratch, used by the once-per-env critic
         self.done_env = torch.zeros((E, 1), dtype=torch.uint8, device=dev)
         self.done_env_in = torch.zeros((self.done_in.shape[0], E, 1), dtype=torch.uint8, device=dev)
@@ -100,7 +101,8 @@ class RecLearner:
         self.dep_std = self.continuous and not getattr(action_head, "independent_std", True)
         for u in range(self.U):
             rep_env = env.clone(env_offset=getattr(env, "env_offset", 0) + (self.rank * self.U + u) * self.E)
-            self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous))
+            self.reps.append(_RecReplica(rep_env, self.T, self.n_upd, centralised_critic, self.device, self.continuous,
+                                         hidden=int(config.network.get("hidden_state_dim", 128))))
         env0 = self.reps[0].env
         self.A, self.nA = env0.num_agents, env0.action_dim
         config.system.num_agents = self.A
@@ -143,12 +145,13 @@ class RecLearner:
                                           and not c.get("use_layer_norm", False) for c in cfgs)
             return tuple((MLPTorso if default else GenericMLPTorso)(**c) for c in cfgs)
 
-        hsd = int(net.get("hidden_state_dim", 128))
+        hsd = self.Hd = int(net.get("hidden_state_dim", 128))
+        wide = hsd != H  # (a hidden width other than 128 runs the cell step by step on the general layer kernels: general torsos)
         env0 = self.reps[0].env
         obs_shape = getattr(env0, "obs_shape", None)  # (H, W, C) observations for CNN pre-torsos (env.synthetic.obs_shape)
         state_shape = getattr(env0, "state_shape", None) if centralised_critic else obs_shape
-        self.actor_network = RecurrentActor(*torsos(net.actor_network, general=self.dep_std), action_head, self.Oa, hsd, obs_shape)
-        self.critic_network = RecurrentValueNet(*torsos(net.critic_network), centralised_critic, self.Oc, hsd, state_shape)
+        self.actor_network = RecurrentActor(*torsos(net.actor_network, general=self.dep_std or wide), action_head, self.Oa, hsd, obs_shape)
+        self.critic_network = RecurrentValueNet(*torsos(net.critic_network, general=wide), centralised_critic, self.Oc, hsd, state_shape)
         self.actor_network.ctx = self.critic_network.ctx = self.ctx
         self.generic_nets = self.actor_network.generic or self.critic_network.generic
         self.Pa, self.Pc = self.actor_network.num_params, self.critic_network.num_params
@@ -232,8 +235,9 @@ class RecLearner:
             obs = Observation(av, mask, sc)
         dones = st(lambda r: r.dones).bool()
         ts = TimeStep(torch.where(dones[..., 0], 2, 1).to(torch.int8), st(lambda r: r.last_reward), 1.0 - dones.float(), obs, {})
-        hst = HiddenStates(st(lambda r: t32_to_rows(r.h_actor, H, E * A).view(E, A, H)),
-                           st(lambda r: t32_to_rows(r.h_critic, H, E * self.Ac).view(E, self.Ac, H).expand(E, A, H)))
+        D = self.Hd
+        hst = HiddenStates(st(lambda r: t32_to_rows(r.h_actor, D, E * A).view(E, A, D)),
+                           st(lambda r: t32_to_rows(r.h_critic, D, E * self.Ac).view(E, self.Ac, D).expand(E, A, D)))
         env_state = {"step_count": st(lambda r: r.state.step_count), "episode_return": st(lambda r: r.state.ep_return),
                      "episode_length": st(lambda r: r.state.ep_length)}
         return RNNLearnerState(params, OptStates(*opts), key, env_state, ts, dones, hst)
@@ -252,8 +256,8 @@ class RecLearner:
         ws = self.ws_roll
         EAc = E * self.Ac
         for rep in self.reps:  # hstates[0] of this rollout, the state the losses re-unroll from (:219-222)
-            rep.h0_actor.view(EA, H).copy_(t32_to_rows(rep.h_actor, H, EA))
-            rep.h0_critic.view(EAc, H).copy_(t32_to_rows(rep.h_critic, H, EAc))
+            rep.h0_actor.view(EA, self.Hd).copy_(t32_to_rows(rep.h_actor, self.Hd, EA))
+            rep.h0_critic.view(EAc, self.Hd).copy_(t32_to_rows(rep.h_critic, self.Hd, EAc))
         fused = os.environ.get("MAVA_REC_FUSED_STEP", "1") != "0" and not self.generic_nets  # (fused step: default torsos)
         packed = fused and self.matmul_mode == "f16x2" and self.nA <= 16
         if packed:  # the parameters are constant during a rollout: split them once (rec_step_h2.hip)
@@ -302,7 +306,10 @@ class RecLearner:
                 # layer-wise acting step (MAVA_REC_FUSED_STEP=0): the training kernels with T = 1
                 self.actor_network.forward_sequence(pa, ws, rep.agents_view[t : t + 1], 1, d1, rep.h_actor, True, None, 1, EA, E,
                                                     A, training=False)
-                rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
+                if self.Hd == H:
+                    rep.h_actor, ws.hs = ws.hs, rep.h_actor  # the scan's output becomes the carried hidden state
+                else:
+                    rep.h_actor[: EA * self.Hd].copy_(self.actor_network.last_hidden(ws, 1, EA))
                 if self.continuous:
                     ind = not self.dep_std
                     check(lib().mava_seq_sample_continuous_f32(EA, self.nA, self.min_scale, ptr(ws.y), ptr(self.actor_network.log_std(pa)) if ind else None,
@@ -323,7 +330,11 @@ class RecLearner:
                     self.critic_network.forward_sequence(pc, ws, self._critic_x(rep, t, t + 1), self.critic_share, d1,
                                                          rep.h_critic, True, None, 1, EA, E, A, training=False,
                                                          y_out=rep.value[t])
-                rep.h_critic, ws.hs = ws.hs, rep.h_critic
+                if self.Hd == H:
+                    rep.h_critic, ws.hs = ws.hs, rep.h_critic
+                else:
+                    n_c = E if self.critic_agg else EA
+                    rep.h_critic[: n_c * self.Hd].copy_(self.critic_network.last_hidden(ws, 1, n_c))
                 rep.env.step_into(rep.state, step + 1, rep.obs_slot(t + 1), rep.reward[t], rep.done[t], rep.info_return[n, t],
                                   rep.info_length[n, t], rep.info_terminal[n, t], action=None if self.continuous else rep.action[t])
                 rep.dones.copy_(rep.done[t])

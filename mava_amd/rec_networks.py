@@ -79,8 +79,12 @@ class _RecurrentNet:
 
     def __init__(self, din: int, n_out: int, hidden_state_dim: int = 128, pre_torso=None, post_torso=None, obs_shape=None,
                  heads=None):
-        if hidden_state_dim != H:
-            raise NotImplementedError("the GRU kernels implement hidden_state_dim=128 (network/rnn.yaml default)")
+        # hidden_state_dim = 128 (network/rnn.yaml): the register-resident scan kernels.  Any other width runs the cell one time
+        # step at a time on the general layer kernels (_gru_fwd_steps / _gru_bwd_steps: a T32 dense launch + a gate kernel per
+        # step) and needs the general torsos around it (RecLearner builds them for it).
+        self.Hd = int(hidden_state_dim)
+        if self.Hd < 1:
+            raise ValueError(f"hidden_state_dim must be positive, got {hidden_state_dim}")
         self.din, self.n_out = int(din), int(n_out)
         # Torsos other than network/rnn.yaml's [128] relu (any layer sizes, tanh, layer norm: mava/networks.py:39-58) run on
         # the general layer kernels (mava_amd/generic_networks.py) around the same GRU scans; the fused acting step and the
@@ -88,16 +92,19 @@ class _RecurrentNet:
         from .generic_networks import CNNTorso, GenericMLPTorso, GenericNet
 
         self.generic = isinstance(pre_torso, (GenericMLPTorso, CNNTorso)) or isinstance(post_torso, GenericMLPTorso)
+        if self.Hd != H and not self.generic:
+            raise ValueError("hidden_state_dim != 128 runs on the general torsos (GenericMLPTorso / CNNTorso)")
         if self.generic:
             if isinstance(post_torso, CNNTorso):
                 raise ValueError("post_torso consumes the 128 hidden features: it cannot be a CNNTorso (network/rcnn.yaml: MLPTorso)")
             # network/rcnn.yaml: CNNTorso pre-torso on (H, W, C) observations (im2col + the same products, section 3.11)
             self.pre = GenericNet(pre_torso, self.din, [], obs_shape=obs_shape if isinstance(pre_torso, CNNTorso) else None)
             # heads of the post-torso: one Dense(n_out), or ContinuousActionHead(independent_std=False)'s mean and log_std layers
-            self.post = GenericNet(post_torso, H, heads or [("head", self.n_out, self.head_scale)])
+            Hd = self.Hd
+            self.post = GenericNet(post_torso, Hd, heads or [("head", self.n_out, self.head_scale)])
             Np, off = self.pre.feat, self.pre.num_params
             segs = []
-            for name, shape in (("Wi", (Np, G3)), ("bi", (G3,)), ("Wh", (H, G3)), ("bhn", (H,))):
+            for name, shape in (("Wi", (Np, 3 * Hd)), ("bi", (3 * Hd,)), ("Wh", (Hd, 3 * Hd)), ("bhn", (Hd,))):
                 segs.append((name, shape, off))
                 off += math.prod(shape)
             self.post_off = off
@@ -122,11 +129,12 @@ class _RecurrentNet:
         if self.generic:
             flat[: self.pre.num_params].copy_(self.pre.init_flat(seed))
             flat[self.post_off : self.post_off + self.post.num_params].copy_(self.post.init_flat(seed + 1))
-            self.seg(flat, "Wi").copy_(torch.randn((self.Np, G3), generator=gen) / math.sqrt(self.Np))
+            Hd = self.Hd
+            self.seg(flat, "Wi").copy_(torch.randn((self.Np, 3 * Hd), generator=gen) / math.sqrt(self.Np))
             for g in range(3):
-                blk = torch.empty(H, H)
+                blk = torch.empty(Hd, Hd)
                 _orthogonal_(blk, 1.0, gen)
-                self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(blk)
+                self.seg(flat, "Wh")[:, g * Hd : (g + 1) * Hd].copy_(blk)
             return flat.to(device) if device is not None else flat
         _orthogonal_(self.seg(flat, "Wpre"), math.sqrt(2.0), gen)
         self.seg(flat, "Wi").copy_(torch.randn((H, G3), generator=gen) / math.sqrt(H))
@@ -142,10 +150,11 @@ class _RecurrentNet:
         ex = (lambda v: v.expand(*lead, *v.shape)) if lead else (lambda v: v)
         Wi, bi, Wh = self.seg(flat, "Wi"), self.seg(flat, "bi"), self.seg(flat, "Wh")
         if self.generic:
+            D = self.Hd
             cell = {
-                "ir": {"kernel": ex(Wi[:, :H]), "bias": ex(bi[:H])}, "iz": {"kernel": ex(Wi[:, H : 2 * H]), "bias": ex(bi[H : 2 * H])},
-                "in": {"kernel": ex(Wi[:, 2 * H :]), "bias": ex(bi[2 * H :])}, "hr": {"kernel": ex(Wh[:, :H])},
-                "hz": {"kernel": ex(Wh[:, H : 2 * H])}, "hn": {"kernel": ex(Wh[:, 2 * H :]), "bias": ex(self.seg(flat, "bhn"))},
+                "ir": {"kernel": ex(Wi[:, :D]), "bias": ex(bi[:D])}, "iz": {"kernel": ex(Wi[:, D : 2 * D]), "bias": ex(bi[D : 2 * D])},
+                "in": {"kernel": ex(Wi[:, 2 * D :]), "bias": ex(bi[2 * D :])}, "hr": {"kernel": ex(Wh[:, :D])},
+                "hz": {"kernel": ex(Wh[:, D : 2 * D])}, "hn": {"kernel": ex(Wh[:, 2 * D :]), "bias": ex(self.seg(flat, "bhn"))},
             }
             fpost = flat[self.post_off : self.post_off + self.post.num_params]
             tree = {"pre_torso": self.pre.torso_tree(flat[: self.pre.num_params], lead), "ScannedRNN_0": {"GRUCell_0": cell},
@@ -224,11 +233,12 @@ class _RecurrentNet:
         dep_std = "action_head" in p and isinstance(p["action_head"].get("log_std", None), dict)  # a Dense layer's {kernel, bias}
         if dep_std:
             self.post.load_head_leaf(p["action_head"]["log_std"], 1, fpost)
+        D = self.Hd
         for g, (ik, hk) in enumerate((("ir", "hr"), ("iz", "hz"), ("in", "hn"))):
-            self.seg(flat, "Wi")[:, g * H : (g + 1) * H].copy_(leaf(cell[ik]["kernel"], (self.Np, H)))
-            self.seg(flat, "bi")[g * H : (g + 1) * H].copy_(leaf(cell[ik]["bias"], (H,)))
-            self.seg(flat, "Wh")[:, g * H : (g + 1) * H].copy_(leaf(cell[hk]["kernel"], (H, H)))
-        self.seg(flat, "bhn").copy_(leaf(cell["hn"]["bias"], (H,)))
+            self.seg(flat, "Wi")[:, g * D : (g + 1) * D].copy_(leaf(cell[ik]["kernel"], (self.Np, D)))
+            self.seg(flat, "bi")[g * D : (g + 1) * D].copy_(leaf(cell[ik]["bias"], (D,)))
+            self.seg(flat, "Wh")[:, g * D : (g + 1) * D].copy_(leaf(cell[hk]["kernel"], (D, D)))
+        self.seg(flat, "bhn").copy_(leaf(cell["hn"]["bias"], (D,)))
         if "action_head" in p and "log_std" in p["action_head"] and not dep_std:
             flat[self.num_net_params : self.num_net_params + self.n_out].copy_(leaf(p["action_head"]["log_std"], (self.n_out,)))
         return flat
@@ -244,6 +254,71 @@ class _RecurrentNet:
                            torch.empty(ws.rows * self.Np, device=dev) if training else None)
         return ws.gen[key]
 
+    def _bufs(self, ws: RecWorkspace, training: bool):
+        """The GRU's activation buffers: the workspace's own (128 wide) or, for another hidden width, this network's (same names)."""
+        if self.Hd == H:
+            return ws
+        key = (id(self), training, "gru")
+        if not hasattr(ws, "gen"):
+            ws.gen = {}
+        if key not in ws.gen:
+            from types import SimpleNamespace
+
+            D, dev = self.Hd, ws.hs.device
+            f = lambda n: torch.empty(ws.rows * n, device=dev)
+            b = SimpleNamespace(gi=f(3 * D), hs=f(D), hprev=f(D), saved=f(4 * D) if training else None)
+            if training:
+                b.dh_out, b.dgi, b.dgh = f(D), f(3 * D), f(3 * D)
+            ws.gen[key] = b
+        return ws.gen[key]
+
+    def last_hidden(self, ws: RecWorkspace, T: int, Rm: int, training: bool = False) -> torch.Tensor:
+        """T32 (Rm x hidden) state after the last step of the sequence batch forward_sequence has just run."""
+        D = self.Hd
+        return self._bufs(ws, training).hs[(T - 1) * Rm * D : T * Rm * D]
+
+    # ---- the cell one step at a time (hidden_state_dim != 128): csrc/generic_layers.hip mava_t32_gru_*
+    def _gru_fwd_steps(self, flat, b, done_ext, h0, h0_t32, idx, T, Rm, E, A, training: bool) -> None:
+        D, L, s = self.Hd, lib(), stream_ptr()
+        dev = b.hs.device
+        if h0_t32:
+            h_in = h0
+        else:  # external (E, A, D) state of the selected envs -> T32 rows (off the hot path: this whole route is the slow one)
+            hv = h0.reshape(E, A, D)
+            hv = hv if idx is None else hv.index_select(0, idx.long())
+            h_in = rows_to_t32(hv.reshape(Rm, D).float().contiguous())
+        gh = torch.empty(Rm * 3 * D, device=dev)
+        Wh, bhn = self.seg(flat, "Wh"), self.seg(flat, "bhn")
+        EA = E * A
+        dptr = lambda t: done_ext.data_ptr() + t * EA
+        check(L.mava_t32_gru_mask_f32(ptr(h_in), dptr(0), ptr(idx), E, A, D, Rm, ptr(b.hprev), s), "mava_t32_gru_mask_f32")
+        f4 = lambda buf, n, t: buf.data_ptr() + 4 * t * Rm * n
+        for t in range(T):
+            self.pre._dense(f4(b.hprev, D, t), D, D, Wh, None, gh, 3 * D, Rm, what="gru_step(gh)")
+            nxt = t + 1 < T
+            check(L.mava_t32_gru_gates_f32(f4(b.gi, 3 * D, t), ptr(gh), ptr(bhn), f4(b.hprev, D, t), D, Rm, f4(b.hs, D, t),
+                                           f4(b.saved, 4 * D, t) if (training and b.saved is not None) else None,
+                                           f4(b.hprev, D, t + 1) if nxt else None, dptr(t + 1) if nxt else None, ptr(idx), E, A, s),
+                  "mava_t32_gru_gates_f32")
+
+    def _gru_bwd_steps(self, flat, b, done_ext, idx, T, Rm, E, A) -> None:
+        D, L, s = self.Hd, lib(), stream_ptr()
+        dev = b.hs.device
+        WhT = self.seg(flat, "Wh").t().contiguous()
+        acc = [torch.empty(Rm * D, device=dev) for _ in range(2)]
+        dhp = [torch.empty(Rm * D, device=dev) for _ in range(2)]
+        EA = E * A
+        dptr = lambda t: done_ext.data_ptr() + t * EA
+        f4 = lambda buf, n, t: buf.data_ptr() + 4 * t * Rm * n
+        for t in range(T - 1, -1, -1):
+            nxt = t + 1 < T
+            check(L.mava_t32_gru_gates_bwd_f32(f4(b.saved, 4 * D, t), f4(b.hprev, D, t), f4(b.dh_out, D, t),
+                                               ptr(acc[(t + 1) & 1]) if nxt else None, ptr(dhp[(t + 1) & 1]) if nxt else None,
+                                               dptr(t + 1) if nxt else None, ptr(idx), E, A, D, Rm, f4(b.dgi, 3 * D, t),
+                                               f4(b.dgh, 3 * D, t), ptr(dhp[t & 1]), s), "mava_t32_gru_gates_bwd_f32")
+            if t > 0:  # gradient into the state entering step t (the reset of step t is applied where it is consumed)
+                self.pre._dense(f4(b.dgh, 3 * D, t), 3 * D, 3 * D, WhT, None, acc[t & 1], D, Rm, what="gru_step(dh)")
+
     def _apply_sequence(self, params: Any, hstate: torch.Tensor, x: torch.Tensor, done: torch.Tensor):
         """Shared body of RecurrentActor.apply / RecurrentValueNet.apply: x (T, E, A, din), done (T, E, A),
         hstate (E, A, 128) -> (new hstate (E, A, 128), outputs (T, E, A, n_out)).  Rows are padded to a multiple
@@ -258,15 +333,16 @@ class _RecurrentNet:
         xp[:, :R] = x.reshape(T, R, self.din).float()
         dp = torch.zeros((T, Rp), dtype=torch.uint8, device=dev)
         dp[:, :R] = done.reshape(T, R).to(torch.uint8)
-        hp = torch.zeros((Rp, H), device=dev)
-        hp[:R] = hstate.reshape(R, H).float()
+        D = self.Hd
+        hp = torch.zeros((Rp, D), device=dev)
+        hp[:R] = hstate.reshape(R, D).float()
         ws = RecWorkspace(T * Rp, max(self.n_out, 1), dev, training=False)
         # the padded batch is presented as Rp single-agent "envs", identity permutation
         y = self.forward_sequence(flat, ws, xp, 1, dp, hp, False, None, T, Rp, Rp, 1, training=False)
         out = t32_to_rows(y, self.n_out, T * Rp).view(T, Rp, self.n_out)[:, :R].reshape(T, E, A, self.n_out)
         self._applied_second = (t32_to_rows(ws.y2, self.n_out, T * Rp).view(T, Rp, self.n_out)[:, :R].reshape(T, E, A, self.n_out)
                                 if ws.y2 is not None else None)
-        h_last = t32_to_rows(ws.hs[(T - 1) * Rp * H : T * Rp * H], H, Rp)[:R].reshape(E, A, H)
+        h_last = t32_to_rows(self.last_hidden(ws, T, Rp), D, Rp)[:R].reshape(E, A, D)
         return h_last, out
 
     # ------------------------------------------------------------------------------------- kernels
@@ -282,14 +358,19 @@ class _RecurrentNet:
             from .generic_networks import GenericNet
 
             wpre, wpost, _ = self._gen_ws(ws, training)
+            b = self._bufs(ws, training)
             feat = self.pre.forward(flat[: self.pre.num_params], wpre, x_ext, x_share, idx, Rm, E, A, T=T)[0]
-            self.pre._dense(feat.data_ptr(), self.Np, self.Np, self.seg(flat, "Wi"), self.seg(flat, "bi"), ws.gi, G3, rows, what="rec_dense(gi)")
-            launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
-                   ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
+            self.pre._dense(feat.data_ptr(), self.Np, self.Np, self.seg(flat, "Wi"), self.seg(flat, "bi"), b.gi, 3 * self.Hd, rows,
+                            what="rec_dense(gi)")
+            if self.Hd == H:
+                launch(f"gru_scan_fwd:{Rm}", L.mava_gru_scan_fwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(h0), int(h0_t32), W("Wh"), W("bhn"),
+                       ptr(ws.gi), ptr(ws.hs), ptr(ws.hprev) if training else None, ptr(ws.saved) if training else None, s)
+            else:
+                self._gru_fwd_steps(flat, b, done_ext, h0, h0_t32, idx, T, Rm, E, A, training)
             if stop_after_scan:
                 raise NotImplementedError("the fused output path serves the default torsos only")
             outs = self.post.forward(flat[self.post_off : self.post_off + self.post.num_params], wpost, None, 1, None, rows, rows, 1,
-                                     x_t32=ws.hs)
+                                     x_t32=b.hs)
             y = outs[0]
             dst = ws.y if y_out is None else y_out  # (the losses / sampling kernels read the workspace's output buffer)
             dst.view(-1)[: y.numel()].copy_(y)
@@ -356,27 +437,36 @@ class _RecurrentNet:
             from .generic_networks import GenericNet
 
             wpre, wpost, dfeat = self._gen_ws(ws, True)
+            b = self._bufs(ws, True)
+            D = self.Hd
             fpost = flat[self.post_off : self.post_off + self.post.num_params]
             gpost = grad_out[self.post_off : self.post_off + self.post.num_params]
             self.post.backward(fpost, wpost, [ws.dy] + ([ws.dy2] if len(self.post.heads) > 1 else []), gpost, accumulate, grad_scale,
-                               dx_out=ws.dh_out)
-            launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
-                   ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), 1, s)  # (dgh: the n third alone)
+                               dx_out=b.dh_out)
+            if D == H:
+                launch(f"gru_scan_bwd:{Rm}", L.mava_gru_scan_bwd_f32, ctx_ptr(self.ctx), T, Rm, E, A, ptr(idx), ptr(done_ext), ptr(self.seg(flat, "Wh")),
+                       ptr(ws.saved), ptr(ws.hprev), ptr(ws.dh_out), ptr(ws.dgi), ptr(ws.dgh), 1, s)  # (dgh: the n third alone)
+            else:
+                self._gru_bwd_steps(flat, b, done_ext, idx, T, Rm, E, A)
             o = lambda n: self.off[n][0]
             Np = self.Np
-            self.pre._xty(wpre.feat_in.data_ptr(), Np, Np, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * G3],
-                            grad_out[o("bi") : o("bi") + G3], 1.0 / grad_scale, accumulate)
+            self.pre._xty(wpre.feat_in.data_ptr(), Np, Np, b.dgi, 3 * D, rows, wpre.slabs, grad_out[o("Wi") : o("Wi") + Np * 3 * D],
+                            grad_out[o("bi") : o("bi") + 3 * D], 1.0 / grad_scale, accumulate)
             # dW_h, and db_hn = the n part of colsum(dgh) (taken from a scratch vector: r and z have no hidden-side bias)
-            tmp_b = torch.empty(G3, device=flat.device)
-            self.pre._xty(ws.hprev.data_ptr(), H, H, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
-                            1.0 / grad_scale, accumulate, gb_accumulate=False, y_tail=ws.dgh, y_split=2 * H)
-            gbhn = grad_out[o("bhn") : o("bhn") + H]
-            if accumulate:
-                gbhn.add_(tmp_b[2 * H :])
+            tmp_b = torch.empty(3 * D, device=flat.device)
+            if D == H:  # dgh = [dgi's r and z thirds | ws.dgh]
+                self.pre._xty(ws.hprev.data_ptr(), H, H, ws.dgi, G3, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + H * G3], tmp_b,
+                                1.0 / grad_scale, accumulate, gb_accumulate=False, y_tail=ws.dgh, y_split=2 * H)
             else:
-                gbhn.copy_(tmp_b[2 * H :])
+                self.pre._xty(b.hprev.data_ptr(), D, D, b.dgh, 3 * D, rows, wpre.slabs, grad_out[o("Wh") : o("Wh") + D * 3 * D], tmp_b,
+                                1.0 / grad_scale, accumulate, gb_accumulate=False)
+            gbhn = grad_out[o("bhn") : o("bhn") + D]
+            if accumulate:
+                gbhn.add_(tmp_b[2 * D :])
+            else:
+                gbhn.copy_(tmp_b[2 * D :])
             WiT = self.seg(flat, "Wi").t().contiguous()
-            self.pre._dense(ws.dgi.data_ptr(), G3, G3, WiT, None, dfeat, Np, rows, what="rec_dense(bwd)")
+            self.pre._dense(b.dgi.data_ptr(), 3 * D, 3 * D, WiT, None, dfeat, Np, rows, what="rec_dense(bwd)")
             self.pre.backward(flat[: self.pre.num_params], wpre, [], grad_out[: self.pre.num_params], accumulate, grad_scale, d_feat=dfeat)
             return
         # transposed weights for the dX = dY W^T products (tiny, re-materialised per call)

@@ -77,7 +77,8 @@ def run_experiment(_config: Config, learner_setup: Callable, make_env: Callable,
     # evaluator.py:175-207: feed-forward or recurrent act function over actor_network.apply
     if recurrent:
         act_fn = make_rec_eval_act_fn(actor_network.apply, config)
-        init_act_state = {"hidden_state": torch.zeros((eval_env.num_envs, eval_env.num_agents, 128), device=eval_env.device)}
+        init_act_state = {"hidden_state": torch.zeros((eval_env.num_envs, eval_env.num_agents, int(config.network.get("hidden_state_dim", 128))),
+                                                      device=eval_env.device)}  # rec_mappo.py:623-629: ScannedRNN.initialize_carry(hidden_state_dim)
     else:
         act_fn, init_act_state = make_ff_eval_act_fn(actor_network.apply, config), None
     evaluator = get_eval_fn(eval_env, act_fn, config, absolute_metric=False)

@@ -38,8 +38,9 @@ class OracleRecLearner:
                      for u in range(U)]
         self.obs = [e.reset(0) for e in self.envs]
         self.dones = [np.zeros((E, A), bool) for _ in range(U)]
-        self.ha = [np.zeros((E * A, 128)) for _ in range(U)]
-        self.hc = [np.zeros((E * A, 128)) for _ in range(U)]
+        self.Ha, self.Hc = ro.hidden_of(self.Na), ro.hidden_of(self.Nc)  # network.hidden_state_dim
+        self.ha = [np.zeros((E * A, self.Ha)) for _ in range(U)]
+        self.hc = [np.zeros((E * A, self.Hc)) for _ in range(U)]
         self.t_global = 0
         self.counts = [0, 0]
 
@@ -105,8 +106,8 @@ class OracleRecLearner:
                 ga, gc, info = np.zeros_like(self.pa), np.zeros_like(self.pc), np.zeros(3)
                 for u, tr in enumerate(trajs):
                     sel = lambda x: x[:, envs].reshape((T, Em * A) + x.shape[3:])
-                    h0a = tr["h0a"].reshape(E, A, 128)[envs].reshape(Em * A, 128)
-                    h0c = tr["h0c"].reshape(E, A, 128)[envs].reshape(Em * A, 128)
+                    h0a = tr["h0a"].reshape(E, A, self.Ha)[envs].reshape(Em * A, self.Ha)
+                    h0c = tr["h0c"].reshape(E, A, self.Hc)[envs].reshape(Em * A, self.Hc)
                     if self.continuous:
                         # trajectory rows (t*E + env)*A + a of the minibatch, time-major like sel()
                         gid = ((np.arange(T)[:, None, None] * E + np.asarray(envs)[None, :, None]) * A + np.arange(A)[None, None, :]).reshape(-1)

@@ -42,13 +42,18 @@ def rec_param_count(din, no: int) -> int:
 # ---- configurable pre / post torsos (mava/networks.py:39-58 MLPTorso inside RecurrentActor / RecurrentValueNet, :269-331):
 # wherever these functions take `din`, a dict from rec_spec() selects torsos other than network/rnn.yaml's [128] relu.
 # Flat layout = mava_amd/rec_networks.py's general layout: [pre torso layers | Wi | bi | Wh | bhn | post torso layers | head].
-def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False, pre_cnn=None, two_heads=False):
+def rec_spec(din: int, pre_sizes, post_sizes, activation="relu", layer_norm=False, pre_cnn=None, two_heads=False, hidden=128):
     """pre_cnn = dict(shape=(H, W, C), channels, kernels, strides): a CNNTorso pre-torso (mava/networks.py:61-85, configs/network/
     rcnn.yaml) instead of the MLP one; its flattened features feed the GRU.  two_heads: the post-torso carries TWO Dense(no)
     heads - ContinuousActionHead(independent_std=False)'s mean and log_std layers (networks.py:137-141) - and the network's
-    output is their concatenation [mean | raw log_std] (2 no wide)."""
+    output is their concatenation [mean | raw log_std] (2 no wide).  hidden: network.hidden_state_dim (the GRU's width)."""
     return dict(din=int(din), pre=list(pre_sizes or []), post=list(post_sizes), act=activation, ln=bool(layer_norm), pre_cnn=pre_cnn,
-                two_heads=bool(two_heads))
+                two_heads=bool(two_heads), hidden=int(hidden))
+
+
+def hidden_of(net) -> int:
+    """GRU width of a network description (an input width: the default 128; or a rec_spec dict)."""
+    return int(net.get("hidden", H)) if isinstance(net, dict) else H
 
 
 def _heads(spec, no):
@@ -79,8 +84,9 @@ def _spec_counts(spec, no):
 
     n_pre = go.param_count(_pre_spec(spec))
     np_ = _pre_width(spec)
-    n_gru = np_ * 3 * H + 3 * H + H * 3 * H + H
-    n_post = go.param_count(go.spec_mlp(H, spec["post"], _heads(spec, no), spec["act"], spec["ln"]))
+    D = hidden_of(spec)
+    n_gru = np_ * 3 * D + 3 * D + D * 3 * D + D
+    n_post = go.param_count(go.spec_mlp(D, spec["post"], _heads(spec, no), spec["act"], spec["ln"]))
     return n_pre, n_gru, n_post, n_pre + n_gru + n_post
 
 
@@ -90,13 +96,14 @@ def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, d
     n_pre, n_gru, n_post, _ = _spec_counts(spec, no)
     np_ = _pre_width(spec)
     pre_spec = _pre_spec(spec)
-    post_spec = go.spec_mlp(H, spec["post"], _heads(spec, no), spec["act"], spec["ln"])
+    D = hidden_of(spec)
+    post_spec = go.spec_mlp(D, spec["post"], _heads(spec, no), spec["act"], spec["ln"])
     g = flat[n_pre : n_pre + n_gru]
     o = 0
-    Wi = g[o : o + np_ * 3 * H].reshape(np_, 3 * H); o += np_ * 3 * H
-    bi = g[o : o + 3 * H]; o += 3 * H
-    Wh = g[o : o + H * 3 * H].reshape(H, 3 * H); o += H * 3 * H
-    bhn = g[o : o + H]
+    Wi = g[o : o + np_ * 3 * D].reshape(np_, 3 * D); o += np_ * 3 * D
+    bi = g[o : o + 3 * D]; o += 3 * D
+    Wh = g[o : o + D * 3 * D].reshape(D, 3 * D); o += D * 3 * D
+    bhn = g[o : o + D]
     fpost = flat[n_pre + n_gru : n_pre + n_gru + n_post]
     h, ys, hs = h0, [], []
     for t in range(x_seq.shape[0]):
@@ -105,9 +112,9 @@ def _t_generic_forward(flat: torch.Tensor, spec, no: int, x_seq: torch.Tensor, d
         xp = go.forward(flat[:n_pre], pre_spec, x_seq[t], features=True)
         gi = xp @ Wi + bi
         gh = h @ Wh
-        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
-        z = torch.sigmoid(gi[:, H : 2 * H] + gh[:, H : 2 * H])
-        n = torch.tanh(gi[:, 2 * H :] + r * (gh[:, 2 * H :] + bhn))
+        r = torch.sigmoid(gi[:, :D] + gh[:, :D])
+        z = torch.sigmoid(gi[:, D : 2 * D] + gh[:, D : 2 * D])
+        n = torch.tanh(gi[:, 2 * D :] + r * (gh[:, 2 * D :] + bhn))
         h = (1.0 - z) * n + z * h
         ys.append(torch.cat(go.forward(fpost, post_spec, h), -1))  # (one head, or [mean | raw log_std])
     return torch.stack(ys), torch.stack(hs), h

@@ -609,3 +609,78 @@ def test_rec_learner_general_torsos(dev, system, pre, post, act, ln, matmul):
     out = learn(L.learner_state())
     torch.cuda.synchronize()
     assert torch.isfinite(out.train_metrics["total_loss"]).all()
+
+
+@pytest.mark.parametrize("matmul", ["f32", "f16x2"])
+@pytest.mark.parametrize("system,hidden,U", [("rec_mappo", 64, 1), ("rec_ippo", 96, 2), ("rec_ippo", 160, 1)])
+def test_rec_learner_hidden_state_dim(dev, system, hidden, U, matmul):
+    """network.hidden_state_dim != 128 (mava/networks.py:222-266: ScannedRNN(hidden_state_dim) inside RecurrentActor /
+    RecurrentValueNet; rec_mappo.py:623-629 initialises the carry with it): the GRU cell runs one time step at a time on the
+    general layer kernels (mava_t32_gru_* around T32 dense launches).  Whole updates against the oracle with the same width
+    (rec_oracle.rec_spec(hidden=...)), the parameter tree's shapes, learn() and the evaluator's carried state."""
+    from mava_amd import envs
+    from mava_amd.config import compose
+    from mava_amd.systems.ppo import rec_ippo, rec_mappo
+    from oracle.rec_loop import OracleRecLearner
+
+    E, A, O, nA, T, K, M = 16, 4, 10, 5, 6, 2, 2
+    cfg = compose(f"default_{system}", [f"arch.num_envs={E}", f"system.rollout_length={T}", f"system.ppo_epochs={K}",
+                                        f"system.num_minibatches={M}", f"system.update_batch_size={U}"])
+    cfg.env.scenario.task_config.num_agents = A
+    cfg.env.synthetic = {"obs_dim": O, "num_actions": nA}
+    cfg.env.kwargs.time_limit = 4
+    cfg.system.num_updates_per_eval = 2
+    cfg.system.actor_lr, cfg.system.critic_lr = 1e-3, 2e-3
+    cfg.system.matmul_mode = matmul
+    cfg.network.hidden_state_dim = hidden
+    central = system == "rec_mappo"
+    mod = rec_mappo if central else rec_ippo
+    env, eval_env = envs.make(cfg, add_global_state=central, device=dev)
+    learn, actor_network, state = mod.learner_setup(env, (42, 7, 8), cfg, device=dev)
+    L = learn.learner
+    Oc = A * O if central else A + O
+    spec_a = ro.rec_spec(A + O, [128], [128], "relu", False, hidden=hidden)
+    spec_c = ro.rec_spec(Oc, [128], [128], "relu", False, hidden=hidden)
+    assert L.generic_nets and L.Pa == ro.rec_param_count(spec_a, nA) and L.Pc == ro.rec_param_count(spec_c, 1)
+    cell = state.params.actor_params["params"]["ScannedRNN_0"]["GRUCell_0"]
+    assert cell["ir"]["kernel"].shape == (1, U, 128, hidden) and cell["hn"]["kernel"].shape == (1, U, hidden, hidden)
+    assert cell["hn"]["bias"].shape == (1, U, hidden)
+    assert state.hstates.policy_hidden_state.shape[-3:] == (E, A, hidden)
+    assert torch.equal(actor_network.flat_from_tree(state.params.actor_params), L.p[: L.Pa])
+
+    rng = np.random.default_rng(3)
+    fa = (rng.standard_normal(L.Pa) * 0.1).astype(np.float32)
+    fc = (rng.standard_normal(L.Pc) * 0.1).astype(np.float32)
+    L.p[: L.Pa].copy_(torch.from_numpy(fa))
+    L.p[L.Pa :].copy_(torch.from_numpy(fc))
+    ora = OracleRecLearner(E=E, A=A, O=O, nA=nA, T=T, K=K, M=M, U=U, centralised=central, seed=42, actor_lr=1e-3, critic_lr=2e-3,
+                           time_limit=4, actor_net=spec_a, critic_net=spec_c)
+    ora.set_params(fa, fc)
+    ftol = 1e-5 if matmul == "f32" else 5e-5
+    for n in range(2):
+        perms = [rng.permutation(E).astype(np.int32) for _ in range(K)]
+        L.update(n, permutations=[torch.from_numpy(p).to(dev) for p in perms])
+        torch.cuda.synchronize()
+        res = ora.update(perms)
+        for u in range(U):
+            rep, tr = L.reps[u], ora.last_traj[u]
+            assert np.array_equal(rep.action.cpu().numpy(), tr["action"]), "sampled actions differ"
+            assert tr["done_in"].any()
+            assert_close(rep.value.cpu().numpy(), tr["value"], ftol, "values")
+            assert_close(rep.log_prob.cpu().numpy(), tr["log_prob"], ftol, "log_probs")
+            assert_close(rep.adv.cpu().numpy(), tr["adv"], ftol, "advantages")
+        assert_close(L.train_metrics[n].cpu().numpy(), res["train_metrics"], 1e-4, "train metrics", scale=1.0)
+        if matmul == "f32":
+            assert_close(L.p[: L.Pa].cpu().numpy(), ora.pa, 1e-5, "actor params")
+            assert_close(L.p[L.Pa :].cpu().numpy(), ora.pc, 1e-5, "critic params")
+        else:
+            check_and_sync_f16x2_state(L, ora)
+    out = learn(L.learner_state())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.train_metrics["total_loss"]).all()
+    assert out.learner_state.hstates.policy_hidden_state.shape[-3:] == (E, A, hidden)
+    from mava_amd.evaluator import get_eval_fn, make_rec_eval_act_fn
+
+    ev = get_eval_fn(eval_env, make_rec_eval_act_fn(actor_network.apply, cfg), cfg, absolute_metric=False)
+    m = ev(out.learner_state.params.actor_params, 0, {"hidden_state": torch.zeros((eval_env.num_envs, A, hidden), device=dev)})
+    assert m["episode_return"].shape[0] >= cfg.arch.num_eval_episodes

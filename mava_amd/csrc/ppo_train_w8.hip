@@ -64,6 +64,15 @@ __device__ __forceinline__ f32x4 mfma3w(const Frag& a, const Frag& b, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
 }
+// the same sum when one operand's low term is known to be zero (its product would add exactly 0: same bits, one MFMA less)
+__device__ __forceinline__ f32x4 mfma2w_blo0(const Frag& a, const half8& bhi, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, bhi, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, bhi, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma2w_alo0(const half8& ahi, const Frag& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, b.lo, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, b.hi, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma3k16(const Frag4& a, const Frag4& b, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, c, 0, 0, 0);
@@ -132,6 +141,10 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   constexpr int YSTR = (NO == 8) ? 9 : NO;  // floats per (wave, row) of partial logits: 8 x 32 x YSTR x 4 bytes <= one image
   float* const B3s = reinterpret_cast<float*>(lds + L.small);
   float* const misc = B3s + 32;
+  // xflag[b] != 0: some staged value of x buffer b has a non-zero low f16 term.  Observations that are exact in f16 - flags,
+  // one-hot ids, small integer coordinates: RobotWarehouse's and the synthetic env's whole agents_view - leave it 0, and the
+  // layer-1 product and its weight gradient then skip the x_lo . W product (it would add exactly 0) and the reads of that plane.
+  unsigned* const xflag = reinterpret_cast<unsigned*>(misc + 2);
 
   const int tid = threadIdx.x;
   const int l = tid & 63, v = tid >> 6, i = l & 15, kg = l >> 4;
@@ -274,6 +287,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   const int xsw = 16 * w8_sw(srow);
   auto stage_commit = [&](int buf, const float (&xr)[NR]) {
     u8* base = lds + L.xs + buf * WIMG + WROW * srow;
+    uint32_t lo_any = 0;
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
       const int c = l16 + TPR * k;
@@ -288,13 +302,16 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
         for (int e = 0; e < 2; ++e) { _Float16 x0, x1; split1(xr[2 * k + e], x0, x1); a[e] = x0; b[e] = x1; }
         *reinterpret_cast<half2v*>(qa) = a;
         *reinterpret_cast<half2v*>(qb) = b;
+        lo_any |= __builtin_bit_cast(uint32_t, b) & 0x7FFF7FFFu;
       } else {
         _Float16 x0, x1;
         split1(xr[k], x0, x1);
         *reinterpret_cast<_Float16*>(qa) = x0;
         *reinterpret_cast<_Float16*>(qb) = x1;
+        lo_any |= (uint32_t)__builtin_bit_cast(uint16_t, x1) & 0x7FFFu;
       }
     }
+    if (lo_any != 0) xflag[buf] = 1u;  // (every writer stores the same value)
   };
   auto load_row = [&](uint32_t fr, int& act, float& f0, float& f1, uint32_t& m) {
     act = tk.action[fr];
@@ -372,7 +389,8 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    {
+    const bool x_lo = __builtin_amdgcn_readfirstlane((int)xflag[buf]) != 0;  // (wave-uniform: one branch per phase)
+    if (x_lo) {
       Frag xb[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) xb[nt] = read_row(XSI + 4096 * nt, WPLANE32, rdA[0]);
@@ -385,6 +403,21 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma3w(W1f[s], b[nt], acc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {  // x is exact in f16: hi plane only, two products
+      half8 xb[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const half8*>(XSI + 4096 * nt + rdA[0]);
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        const half8 b[2] = {xb[0], xb[1]};
+        if (s + 1 < S1) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const half8*>(XSI + 4096 * nt + rdA[(s + 1) & 3]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma2w_blo0(W1f[s], b[nt], acc[nt]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -414,6 +447,11 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     WSTAMP(2);
     __syncthreads();  // A: h1 image complete
     WSTAMP(3);
+    // the other x buffer's flag: its last readers (the previous tile's dW1) are behind this barrier, its next writers (this
+    // tile's commit) behind barrier B
+    if constexpr (DO_STAGE) {
+      if (tid == (ROLE == 2 ? 256 : 0)) xflag[buf ^ 1] = 0u;
+    }
 
     // ---------------------------------------------------------------- P2: z2 = b2 + W2^T h1^T ; head partial logits
     f32x4 h2[2];
@@ -600,15 +638,28 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
       // gW1[k][n = 16 v + i] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
       const Frag b = read_tr(DZ1I, WPLANE32, trOwn);
       constexpr int D1 = GWD < KT1 ? GWD : KT1;
-      Frag an[D1];
+      if (x_lo) {
+        Frag an[D1];
 #pragma unroll
-      for (int t = 0; t < D1; ++t) an[t] = read_tr(XSI, WPLANE32, tr_addr(t));
+        for (int t = 0; t < D1; ++t) an[t] = read_tr(XSI, WPLANE32, tr_addr(t));
 #pragma unroll
-      for (int t = 0; t < KT1; ++t) {
-        const Frag a = an[t % D1];
-        if (t + D1 < KT1) an[t % D1] = read_tr(XSI, WPLANE32, tr_addr(t + D1));
-        gW1[t] = mfma3w(a, b, gW1[t]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < KT1; ++t) {
+          const Frag a = an[t % D1];
+          if (t + D1 < KT1) an[t % D1] = read_tr(XSI, WPLANE32, tr_addr(t + D1));
+          gW1[t] = mfma3w(a, b, gW1[t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        half8 an[D1];
+#pragma unroll
+        for (int t = 0; t < D1; ++t) an[t] = read_tr8(XSI + tr_addr(t), WROW);
+#pragma unroll
+        for (int t = 0; t < KT1; ++t) {
+          const half8 a = an[t % D1];
+          if (t + D1 < KT1) an[t % D1] = read_tr8(XSI + tr_addr(t + D1), WROW);
+          gW1[t] = mfma2w_alo0(a, b, gW1[t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     WSTAMP(13);

@@ -338,8 +338,14 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     }
   };
   u8* const xs_dummy = reinterpret_cast<u8*>(misc + 8);  // 16 bytes nobody reads
-  auto stage_commit = [&](int buf, const float (&xr)[NR]) {
+  // wide kernel: xflag[tile parity] != 0 when some staged value of that tile's x rows has a non-zero low f16 term.  Inputs
+  // exact in f16 (flags, one-hot ids, small integers: the whole global state of RobotWarehouse and of the synthetic env) leave
+  // it 0; the loader group's dW1 product then skips x_lo . dz1 (exactly 0) and the reads of that plane - same bits.
+  unsigned* const xflag = reinterpret_cast<unsigned*>(misc + 2);
+  int tpar = 0;  // parity of the tile being processed
+  auto stage_commit = [&](int buf, const float (&xr)[NR], int flag_slot = 0) {
     u8* base = lds + L.xs + buf * 2 * xs_plane + srow * xs_row;
+    uint32_t lo_any = 0;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       const int c = l8 + 8 * i;
@@ -352,6 +358,10 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
         for (int e = 0; e < 4; ++e) { _Float16 x0, x1; split1(xr[4 * i + e], x0, x1); a[e] = x0; b[e] = x1; }
         *reinterpret_cast<half4*>(qa) = a;
         *reinterpret_cast<half4*>(qb) = b;
+        if constexpr (WIDE) {
+          const uint2 bb = __builtin_bit_cast(uint2, b);
+          lo_any |= (bb.x | bb.y) & 0x7FFF7FFFu;
+        }
       } else if (XV == 2) {
         typedef _Float16 half2v __attribute__((ext_vector_type(2)));
         half2v a, b;
@@ -359,12 +369,17 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
         for (int e = 0; e < 2; ++e) { _Float16 x0, x1; split1(xr[2 * i + e], x0, x1); a[e] = x0; b[e] = x1; }
         *reinterpret_cast<half2v*>(qa) = a;
         *reinterpret_cast<half2v*>(qb) = b;
+        if constexpr (WIDE) lo_any |= __builtin_bit_cast(uint32_t, b) & 0x7FFF7FFFu;
       } else {
         _Float16 x0, x1;
         split1(xr[i], x0, x1);
         *reinterpret_cast<_Float16*>(qa) = x0;
         *reinterpret_cast<_Float16*>(qb) = x1;
+        if constexpr (WIDE) lo_any |= (uint32_t)__builtin_bit_cast(uint16_t, x1) & 0x7FFFu;
       }
+    }
+    if constexpr (WIDE) {
+      if (lo_any != 0) xflag[flag_slot] = 1u;  // (every writer stores the same value)
     }
   };
 
@@ -436,7 +451,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
   }
 
   STAMP_DECL
-  for (; it < ntiles; it += gridDim.x, buf ^= (WIDE ? 0 : 1)) {
+  for (; it < ntiles; it += gridDim.x, buf ^= (WIDE ? 0 : 1), tpar ^= 1) {
     STAMP(14);
     const bool valid = (it * 32 + r) < R;
     const long itn = it + gridDim.x;
@@ -830,11 +845,34 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     __syncthreads();  // D: dz1 image (narrow inputs: and the next x tile) complete
     STAMP(12);
     if constexpr (WIDE && CHAIN) do_gw2();  // beside the loader group's dW1 product
+    bool x_lo = true;
+    if constexpr (WIDE && LOADER) {
+      x_lo = __builtin_amdgcn_readfirstlane((int)xflag[tpar]) != 0;
+      // the next tile's flag: its last readers (the tile before this one) are long past, its writers (the commit between
+      // barriers E and F below) come after this
+      if (tid == 0) xflag[tpar ^ 1] = 0u;
+    }
     if constexpr (LOADER) {
       // gW1[k][n = 32w + r] += sum_rows x[row][k] dz1[row][n]   (row din of gW1 = db1 through the ones column)
       constexpr int NPR = 2 * KT1;                          // products
       constexpr int D1 = WIDE ? MAVA_GW_DEPTH_WIDE : GW_DEPTH;  // operand prefetch depth (see do_gw2)
-      if constexpr (D1 > 0) {
+      if (WIDE && D1 > 0 && !x_lo) {  // x exact in f16: hi plane only, two products per step
+        constexpr int DP = (D1 > 0 ? (D1 < NPR ? D1 : NPR) : 1);
+        const Frag b0 = sw_read_tr(DZ1I, SW_PLANE, trS, 0, w), b1 = sw_read_tr(DZ1I, SW_PLANE, trS, 1, w);
+        half8 a[DP];
+#pragma unroll
+        for (int i = 0; i < DP; ++i) a[i] = read_tr8(XSI + trX + 16 * (i / KT1) * xs_row + 2 * (32 * (i % KT1)), xs_row);
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) {
+          const half8 cur = a[i % DP];
+          if (i + DP < NPR) a[i % DP] = read_tr8(XSI + trX + 16 * ((i + DP) / KT1) * xs_row + 2 * (32 * ((i + DP) % KT1)), xs_row);
+          const Frag& b = (i / KT1) ? b1 : b0;
+          f32x16 c = gW1[i % KT1];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, b.lo, c, 0, 0, 0);
+          gW1[i % KT1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, b.hi, c, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (D1 > 0) {
         constexpr int DP = D1 < NPR ? D1 : NPR;
         const Frag b0 = sw_read_tr(DZ1I, SW_PLANE, trS, 0, w), b1 = sw_read_tr(DZ1I, SW_PLANE, trS, 1, w);
         Frag a[DP > 0 ? DP : 1];
@@ -865,7 +903,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if constexpr (WIDE) {
       __syncthreads();  // E: every reader of the (single) x tile is done
       if constexpr (LOADER) {
-        stage_commit(0, xr);  // (without a next tile: row 0 into a buffer nobody reads again)
+        stage_commit(0, xr, tpar ^ 1);  // (without a next tile: row 0 into a buffer nobody reads again)
       }
       __syncthreads();  // F: next x tile visible
     }

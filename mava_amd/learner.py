@@ -346,7 +346,12 @@ class FFLearner:
         main = torch.cuda.current_stream() if self.device.type == "cuda" else None
         side = self.U > 1 and self.timers is None and main is not None and os.environ.get("MAVA_ROLLOUT_STREAMS", "1") != "0"
         if side and not hasattr(self, "_roll_streams"):
-            self._roll_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.U - 1)]
+            from .streams import overlapping_stream
+
+            self._roll_streams = [overlapping_stream(self.device) for _ in range(self.U - 1)]  # (probed for real concurrency)
+            if any(st is None for st in self._roll_streams):
+                self._roll_streams = []
+        side = side and len(self._roll_streams) == self.U - 1
         if side:
             for st in self._roll_streams:  # (before replica 0's launch is queued: the side streams wait for the parameters only)
                 st.wait_stream(main)

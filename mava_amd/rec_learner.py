@@ -185,10 +185,14 @@ class RecLearner:
         # and its products are short launches - alone on the device they left it mostly idle for ~14 ms per update.
         self.overlap_critic = (os.environ.get("MAVA_REC_OVERLAP", "1") != "0" and d.type == "cuda" and not self.generic_nets)
         if self.overlap_critic:
+            from .streams import overlapping_stream
+
+            self.side = overlapping_stream(d)  # (probed: a stream that shares the launch stream's hardware queue is no use)
+            self.overlap_critic = self.side is not None
+        if self.overlap_critic:
             c_rows = self.T * (self.Rmc if self.critic_agg else self.Rm)
             self.ws_c = RecWorkspace(c_rows, 1, d, training=True, din_max=self.Oc)
             self.slabs_c = torch.zeros_like(self.slabs)
-            self.side = torch.cuda.Stream(device=d)
         self.stats = torch.zeros((lib().mava_adv_stats_blocks(), 2), dtype=torch.float64, device=d)
         self.train_metrics = torch.zeros((self.n_upd, self.K, self.M, 4), device=d)
         self.perm_count = 0  # epoch permutations drawn so far (counter of mava_permutation_i32)

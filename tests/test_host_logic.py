@@ -151,3 +151,10 @@ def test_tanh_normal_host_view():
     np.testing.assert_allclose(d.log_prob(torch.from_numpy(a)).numpy(), tn.log_prob(a, loc, ls), rtol=1e-6, atol=1e-6)
     s = d.sample(seed=torch.Generator().manual_seed(0))
     assert s.shape == (6, 3) and float(s.abs().max()) < 1.0 and torch.isfinite(d.entropy(seed=torch.Generator().manual_seed(1))).all()
+
+
+def test_side_stream_probe_without_gpu():
+    """mava_amd/streams.py: no side stream off the GPU (the learners then keep everything on the one stream)."""
+    from mava_amd.streams import overlapping_stream
+
+    assert overlapping_stream("cpu") is None

@@ -46,8 +46,9 @@ enum {
   MAVA_CTX_GAE_VARIANT = 2,        /* bench sweeps (tools/gae_sweep.py): chunk / lane mapping of mava_gae_f32, 0 = default */
   MAVA_CTX_POLICY_VARIANT = 3,     /* 0 = per-wave acting kernel / hybrid launch (default), 1 = per-wave only, 2 = block-cooperative */
   MAVA_CTX_H2_LAUNCHES = 4,        /* diagnostic counter: gradient launches of this handle that ran on the f16x2 kernels */
-  MAVA_CTX_TRAIN_VARIANT = 5,      /* f16x2 gradient kernels: 0 (default) = the eight-wave actor kernel (ppo_train_w8.hip) where it is
-                                      instantiated, 1 = the four-wave kernels (ppo_train_h2.hip) only; for A/B measurements */
+  MAVA_CTX_TRAIN_VARIANT = 5,      /* f16x2 gradient kernels, bit 0: 0 (default) = the eight-wave actor kernel (ppo_train_w8.hip) where it
+                                      is instantiated, 1 = the four-wave kernels (ppo_train_h2.hip) only; bit 1: always run the x_lo
+                                      products that inputs exact in f16 skip (same bits either way: tests); for A/B measurements */
   MAVA_CTX_W8_LAUNCHES = 6,        /* diagnostic counter: ... of which on the eight-wave kernel */
   MAVA_CTX_W1_SPLIT_FRESH = 7      /* read: 1 while the handle's pre-split W1 copy (wide f16x2 critic) already matches the parameters of
                                       the next gradient launch (mava_ppo_finish_f32 wrote it); write 0: the caller changed parameters

@@ -11,7 +11,7 @@ struct mava_ctx {
   int critic_aggregation;  // 1: a critic input row shared by the A agents of an index is evaluated once
   int gae_variant;         // 0: default chunk / lane mapping of mava_gae_f32 (others: tools/gae_sweep.py)
   int policy_variant;      // 0: default acting-step launch (others: tools/policy_bench.py)
-  int train_variant;       // f16x2 gradient kernels: 0 = default (eight-wave actor kernel where instantiated), 1 = four-wave kernels only
+  int train_variant;       // f16x2 gradient kernels: bit 0 = four-wave kernels only (default: eight-wave actor kernel where instantiated); bit 1 = never skip the x_lo products
   long h2_launches;        // diagnostic: gradient launches of this handle that ran on the f16x2 kernels
   long w8_launches;        // diagnostic: ... of which on the eight-wave kernel (ppo_train_w8.hip)
   void* w1_split[2];       // f16x2, inputs wider than 95: pre-split W1 in fragment order (actor, critic), lazily allocated

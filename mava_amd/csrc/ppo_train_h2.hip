@@ -847,7 +847,7 @@ __device__ __forceinline__ void h2_body(const TrainTask& tk, const H2Layout& L, 
     if constexpr (WIDE && CHAIN) do_gw2();  // beside the loader group's dW1 product
     bool x_lo = true;
     if constexpr (WIDE && LOADER) {
-      x_lo = __builtin_amdgcn_readfirstlane((int)xflag[tpar]) != 0;
+      x_lo = __builtin_amdgcn_readfirstlane((int)xflag[tpar]) != 0 || tk.force_xlo != 0;
       // the next tile's flag: its last readers (the tile before this one) are long past, its writers (the commit between
       // barriers E and F below) come after this
       if (tid == 0) xflag[tpar ^ 1] = 0u;
@@ -1090,8 +1090,10 @@ static int h2_dispatch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool acto
 
 // (ctx is never NULL here: a NULL handle means exact f32 and does not reach this file.)  h2_launches counts the launches
 // that really ran on the split-f16 kernel (mava_ctx_get(ctx, MAVA_CTX_H2_LAUNCHES): the parity tests assert it).
-int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
-  if (actor && ctx->train_variant == 0) {
+int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk_in, int n_slab, bool actor, hipStream_t s) {
+  TrainTask tk = tk_in;
+  tk.force_xlo = (ctx->train_variant & 2) != 0;
+  if (actor && (ctx->train_variant & 1) == 0) {
     const int rc8 = mava_train_w8_launch(tk, n_slab, s);
     if (rc8 <= 0) {
       if (rc8 == 0) { ++ctx->h2_launches; ++ctx->w8_launches; }

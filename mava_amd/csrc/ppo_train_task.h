@@ -29,6 +29,7 @@ struct TrainTask {
   float* slab;
   long slab_stride;
   unsigned long long* stamps;  // diagnostic builds only (-DMAVA_STAMPS): per-phase cycle sums of block 0
+  int force_xlo;           // f16x2 kernels: always run the x_lo products (MAVA_CTX_TRAIN_VARIANT bit 1; tests: same bits either way)
 };
 
 // ppo_train_h2.hip: the same fused kernel on v_mfma_f32_32x32x16_f16 with every operand split into two f16 terms

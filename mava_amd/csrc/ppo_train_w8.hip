@@ -389,7 +389,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 
     // ---------------------------------------------------------------- P1: z1 = W1^T x^T (+ b1 through the ones column)
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    const bool x_lo = __builtin_amdgcn_readfirstlane((int)xflag[buf]) != 0;  // (wave-uniform: one branch per phase)
+    const bool x_lo = __builtin_amdgcn_readfirstlane((int)xflag[buf]) != 0 || tk.force_xlo != 0;  // (wave-uniform: one branch per phase)
     if (x_lo) {
       Frag xb[2];
 #pragma unroll

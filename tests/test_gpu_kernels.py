@@ -584,3 +584,47 @@ def test_fused_tail_equals_separate_launches(dev, din_c, mode, big):
             outs.append(slab.clone())
         assert ctx.get(ctx.W1_SPLIT_FRESH) == 0, "the fresh flag is one-shot"
         assert torch.equal(outs[0], outs[1]), "critic gradient on the W1 copy re-split inside the Adam launch"
+
+
+@pytest.mark.parametrize("exact_rows", ["all", "some"])
+def test_f16_exact_inputs_skip_the_low_term_with_the_same_bits(dev, exact_rows):
+    """Observations that are exact in f16 (flags, one-hot ids, small integers: RobotWarehouse's agents_view) have a zero low
+    term: the eight-wave actor kernel and the wide critic's dW1 product then run two MFMAs per product instead of three and
+    never read the low plane.  The skipped product is exactly 0, so slabs must be BIT-identical to the run that is forced
+    through the three-product path (MAVA_CTX_TRAIN_VARIANT bit 1) - with every tile exact, and with exact and inexact tiles
+    mixed in one launch (the flag is per tile)."""
+    from mava_amd import ops
+    from mava_amd._lib import Ctx
+
+    TE, A, O, nA, Rb = 2048, 4, 66, 5, 1536
+    rng = np.random.default_rng(11)
+    av, gs, mask, action, old_lp, adv, old_v, tgt = _traj(rng, TE, A, O, nA)
+    # f16-exact observations: bits, a one-hot id, two small integer coordinates
+    av = (rng.random(av.shape) < 0.2).astype(np.float32)
+    av[:, O : O + A] = np.eye(A, dtype=np.float32)[np.arange(TE * A) % A]
+    av[:, :2] = rng.integers(0, 10, (TE * A, 2)).astype(np.float32)
+    gs = av[:, :O].reshape(TE, A * O).copy()
+    if exact_rows == "some":  # every third (t,e) index carries values with a low term
+        noisy = np.arange(TE) % 3 == 0
+        gs[noisy] += rng.standard_normal((int(noisy.sum()), A * O)).astype(np.float32) * 1e-3
+        av.reshape(TE, A, O + A)[noisy] += rng.standard_normal((int(noisy.sum()), A, O + A)).astype(np.float32) * 1e-3
+    din, dc = O + A, A * O
+    fa, fc = _net(rng, din, nA, 1.0).astype(np.float32), _net(rng, dc, 1, 1.0).astype(np.float32)
+    idx = rng.permutation(TE)[:Rb].astype(np.int32)
+    n_slab = 48
+    out = {}
+    for variant in (0, 2):
+        ctx = Ctx("f16x2")
+        ctx.set(ctx.TRAIN_VARIANT, variant)
+        sa, sc = torch.zeros((n_slab, fa.size + 2), device=dev), torch.zeros((n_slab, fc.size + 2), device=dev)
+        stats = ops.adv_stats(_t(adv, dev), _t(idx, dev), 0, Rb, A)
+        ops.ppo_actor_grad(_t(fa, dev), _t(av, dev), _t(mask, dev), _t(action, dev), _t(old_lp, dev), _t(adv, dev), stats,
+                           _t(idx, dev), 0, Rb, A, nA, 0.2, 0.01, sa, ctx=ctx)
+        ops.ppo_critic_grad(_t(fc, dev), _t(gs, dev), A, _t(old_v, dev), _t(tgt, dev), _t(idx, dev), 0, Rb, A, 0.2, 0.5, sc, ctx=ctx)
+        torch.cuda.synchronize()
+        assert ctx.get(ctx.W8_LAUNCHES) == 1 and ctx.h2_launches == 2
+        out[variant] = (sa.clone(), sc.clone())
+        ctx.close()
+    assert torch.equal(out[0][0], out[2][0]), "actor slabs: two-product path != three-product path"
+    assert torch.equal(out[0][1], out[2][1]), "critic slabs: two-product path != three-product path"
+    assert float(out[0][0].abs().sum()) > 0 and float(out[0][1].abs().sum()) > 0

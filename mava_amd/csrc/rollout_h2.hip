@@ -75,7 +75,7 @@ struct RolloutArgs {
 };
 
 struct RolloutLds {  // byte offsets
-  int xa, xa_row, xa_plane, xc, xc_row, xc_plane, h1, wl, ypa, ypc, act, mask, small, end;
+  int xa, xa_row, xa_plane, xc, xc_row, xc_plane, h1, wl, ypa, ypc, act, mask, small, gum, end;
 };
 constexpr int W1_REG_STEPS = 12;  // layer-1 steps of the critic kept in registers; further steps live in LDS as fragments
 
@@ -98,7 +98,9 @@ RolloutLds make_rollout_lds() {
   L.act = L.ypc + 2 * 4 * 32 * 4;
   L.mask = L.act + 64 * 4;
   L.small = L.mask + 64 * 32;        // f32: b2a[128] b3a[32] b2c[128] b3c[4] w3c[128]
-  L.end = L.small + (128 + 32 + 128 + 4 + 128) * 4;
+  L.gum = L.small + (128 + 32 + 128 + 4 + 128) * 4;  // f32 [64 rows][NO]: the step's Gumbel noise (see the S phase)
+  L.gum = (L.gum + 15) & ~15;
+  L.end = L.gum + 64 * NO * 4;
   L.end = (L.end + 15) & ~15;
   return L;
 }
@@ -121,6 +123,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   float* const W3c = B3c + 4;
   int* const ACT = reinterpret_cast<int*>(lds + L.act);
   u8* const MASK = lds + L.mask;       // [64 rows][32]
+  float* const GUM = reinterpret_cast<float*>(lds + L.gum);  // [64 rows][NO]
   float* const YPA = reinterpret_cast<float*>(lds + L.ypa);
   float* const YPC = reinterpret_cast<float*>(lds + L.ypc);
   const int xa_row = L.xa_row, xa_plane = L.xa_plane, xc_row = L.xc_row, xc_plane = L.xc_plane;
@@ -243,7 +246,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   // for both roles; `active` = false keeps only the barriers: the actor group during the bootstrap pass)
   constexpr int NT = ACT_ROLE ? 2 : NTC;  // 32-row tiles of this role
   RSTAMP_DECL
-  auto forward = [&](bool active) __attribute__((always_inline)) {
+  auto forward = [&](bool active, bool noise, uint32_t noise_step) __attribute__((always_inline)) {
     f32x16 z[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -287,6 +290,23 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         for (int q = 0; q < 16; ++q) z[i][q] = fmaxf(z[i][q], 0.0f);
         half4 ph[4], pl[4];
         write_image(lds + L.h1 + ((ACT_ROLE ? 0 : 2) + i) * IMG_BYTES, r, 32 * w + 4 * h, z[i], ph, pl);
+      }
+    }
+    if (ACT_ROLE && noise) {
+      // The step's Gumbel noise -log(-log u) does not depend on the network: it is drawn HERE, where the actor group used
+      // to wait ~750 cycles for the critic group's wider layer 1, instead of inside the sampling phase (two passes of a
+      // Philox4x32-10 call and two logarithms per lane were ~1.8 K of that phase's 5.5 K cycles).  One call per
+      // (row, four outputs): thread (row = tid / 4, c = tid % 4) draws outputs 4 c .. 4 c + 3; same counters, same values.
+      const int grow = tid >> 2, c = tid & 3;
+      if (c < NO / 4) {
+        const uint32_t gid = a.row_offset + (uint32_t)(e0 * A + grow);
+        const Philox4 rnd = philox4x32_10(gid, noise_step, (uint32_t)c, POLICY_STREAM, a.pseed_lo, a.pseed_hi);
+        float4 g;
+        g.x = -logf(-logf(u01_open(rnd.x)));
+        g.y = -logf(-logf(u01_open(rnd.y)));
+        g.z = -logf(-logf(u01_open(rnd.z)));
+        g.w = -logf(-logf(u01_open(rnd.w)));
+        *reinterpret_cast<float4*>(GUM + grow * NO + 4 * c) = g;
       }
     }
     RSTAMP(0);
@@ -445,7 +465,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
 
   for (int t = 0; t < a.T; ++t) {
     const uint32_t step = a.t0 + (uint32_t)t;
-    forward(true);
+    forward(true, true, step);
     // ---------------------------------------------------------------- S: sample, log-prob, value -> slot t
     // (the sample and observation-generation code runs on the actor group: the critic group's registers are full of
     // weights; it writes the values and does the per-agent bookkeeping meanwhile)
@@ -465,11 +485,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         const float logp = z - (mx + logf(se));
         // Gumbel-max: argmax_o z[o] - log(-log(u_o)), first index wins ties (jax.random.categorical; the noise is
         // this library's Philox stream: counter (global row, step, o / 4, "POLI"))
-        const uint32_t gid = a.row_offset + (uint32_t)(e0 * A + row);
-        const Philox4 rnd = philox4x32_10(gid, step, (uint32_t)(o >> 2), POLICY_STREAM, a.pseed_lo, a.pseed_hi);
-        const uint32_t wds[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-        const float u = u01_open(wds[o & 3]);
-        float sc = (o < no) ? (z + (-logf(-logf(u)))) : -FLT_MAX;
+        // (drawn before barrier 1 of this step: see forward())
+        float sc = (o < no) ? (z + GUM[row * NO + o]) : -FLT_MAX;
         if (!(sc > -FLT_MAX)) sc = -FLT_MAX;  // padded / fully masked rows: index 0 wins like the sequential scan
         int best = o;
 #pragma unroll
@@ -587,7 +604,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
 #endif
   // ------------------------------------------------------------------ bootstrap value (ff_mappo.py:109-110)
   write_out((long)a.T, ACT_ROLE);  // the last observation
-  forward(!ACT_ROLE);
+  forward(!ACT_ROLE, false, 0u);
   if (bk_on) {
     const float lv = value_of(SHARED ? tid / A : tid);
     a.last_val[bk_k] = lv;

@@ -75,7 +75,7 @@ struct RolloutArgs {
 };
 
 struct RolloutLds {  // byte offsets
-  int xa, xa_row, xa_plane, xc, xc_row, xc_plane, h1, wl, ypa, ypc, act, mask, small, gum, end;
+  int xa, xa_row, xa_plane, xc, xc_row, xc_plane, h1, wl, ypa, ypc, act, mask, small, gum, xlf, end;
 };
 constexpr int W1_REG_STEPS = 12;  // layer-1 steps of the critic kept in registers; further steps live in LDS as fragments
 
@@ -100,7 +100,8 @@ RolloutLds make_rollout_lds() {
   L.small = L.mask + 64 * 32;        // f32: b2a[128] b3a[32] b2c[128] b3c[4] w3c[128]
   L.gum = L.small + (128 + 32 + 128 + 4 + 128) * 4;  // f32 [64 rows][NO]: the step's Gumbel noise (see the S phase)
   L.gum = (L.gum + 15) & ~15;
-  L.end = L.gum + 64 * NO * 4;
+  L.xlf = L.gum + 64 * NO * 4;  // u32: != 0 when some value of the slot-0 observations has a non-zero low f16 term
+  L.end = L.xlf + 16;
   L.end = (L.end + 15) & ~15;
   return L;
 }
@@ -124,6 +125,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   int* const ACT = reinterpret_cast<int*>(lds + L.act);
   u8* const MASK = lds + L.mask;       // [64 rows][32]
   float* const GUM = reinterpret_cast<float*>(lds + L.gum);  // [64 rows][NO]
+  unsigned* const XLF = reinterpret_cast<unsigned*>(lds + L.xlf);
   float* const YPA = reinterpret_cast<float*>(lds + L.ypa);
   float* const YPC = reinterpret_cast<float*>(lds + L.ypc);
   const int xa_row = L.xa_row, xa_plane = L.xa_plane, xc_row = L.xc_row, xc_plane = L.xc_plane;
@@ -192,6 +194,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
   // x images of slot 0 (written by the previous rollout or the reset), ones (bias) columns, masks of slot 0
   {
     const long slot0_av = 0;
+    uint32_t lo_any = 0;
     for (int i = t512; i < 64 * W; i += 512) {
       const int row = i / W, c = i - row * W;
       const int e = e0 + row / A;
@@ -201,6 +204,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
       u8* p = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row + 2 * c;
       *reinterpret_cast<_Float16*>(p) = x0;
       *reinterpret_cast<_Float16*>(p + xa_plane) = x1;
+      lo_any |= (uint32_t)__builtin_bit_cast(uint16_t, x1) & 0x7FFFu;
     }
     if (t512 < 64) {
       u8* p = lds + L.xa + (t512 >> 5) * 2 * xa_plane + (t512 & 31) * xa_row + 2 * din_a;
@@ -216,6 +220,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         u8* p = lds + L.xc + le * xc_row + 2 * c;
         *reinterpret_cast<_Float16*>(p) = x0;
         *reinterpret_cast<_Float16*>(p + xc_plane) = x1;
+        lo_any |= (uint32_t)__builtin_bit_cast(uint16_t, x1) & 0x7FFFu;
       }
       if (t512 < XC_ROWS) *reinterpret_cast<_Float16*>(lds + L.xc + t512 * xc_row + 2 * din_c) = (_Float16)1.0f;
     }
@@ -223,6 +228,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
       const int row = i / no, o = i - row * no;
       MASK[row * 32 + o] = (e0 + row / A < E) ? a.action_mask[((long)e0 * A + row) * no + o] : 1;
     }
+    if (lo_any != 0) *XLF = 1u;  // (every writer stores the same value; zeroed with the rest of the LDS above)
   }
   __syncthreads();
 
@@ -238,6 +244,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
     er_reg = a.ep_return[e0 + bk_le]; el_reg = a.ep_length[e0 + bk_le];
   }
 
+  // The env phase below writes only the HIGH plane of the x images (its observations are exact in f16): when the slot-0
+  // observations loaded above are exact too, the low plane is zero for the whole rollout, and layer 1 runs two MFMAs per
+  // product instead of three without reading that plane (the skipped product is exactly 0: same bits).
+  const bool x_lo = __builtin_amdgcn_readfirstlane((int)*XLF) != 0;
   const int rowB = r * IMG_ROW + 16 * h;  // + 32 s: features 16s + 8h .. + 7 of image row r
   const long EA = (long)E * A;
   const uint32_t nch = (O - 2 + 15) / 16 > 0 ? (O - 2 + 15) / 16 : 1;  // bit chunks per raw view
@@ -265,6 +275,12 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         wf.lo = __builtin_bit_cast(half8, WL[512 * (s - S1REG) + 1]);
         return wf;
       };
+      auto x_hi = [&](int s, int t) -> half8 {
+        return (!ACT_ROLE && SHARED)
+                   ? *reinterpret_cast<const half8*>(lds + L.xc + (r & (XC_ROWS - 1)) * xc_row + 16 * h + 32 * s)
+                   : *reinterpret_cast<const half8*>(lds + L.xa + t * 2 * xa_plane + r * xa_row + 16 * h + 32 * s);
+      };
+      if (x_lo) {
       Frag bn[NT], wn;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bn[t] = x_frag(0, t);
@@ -283,6 +299,31 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
 #pragma unroll
         for (int t = 0; t < NT; ++t) z[t] = mfma3(wf, b[t], z[t]);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {  // observations exact in f16: high plane only, two products
+      half8 bn[NT];
+      Frag wn;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bn[t] = x_hi(0, t);
+      if (S1REG == 0) wn = w_frag(0);
+#pragma unroll
+      for (int s = 0; s < S1R; ++s) {
+        half8 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = bn[t];
+        const Frag wf = (s < S1REG) ? W1r[s < S1REG ? s : 0] : wn;
+        if (s + 1 < S1R) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bn[t] = x_hi(s + 1, t);
+          if (s + 1 >= S1REG) wn = w_frag(s + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          z[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.lo, b[t], z[t], 0, 0, 0);
+          z[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.hi, b[t], z[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {

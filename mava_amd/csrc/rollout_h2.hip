@@ -580,15 +580,47 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs& a, const Rollout
         const int n = (int)min(16u, (uint32_t)O - f0);
         u8* xa = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row;
         u8* xc = lds + L.xc + le * xc_row + 2 * (ag * O);
+        // a full chunk on 4-byte aligned targets: eight 4-byte stores per image (pairs of f16 0.0 / 1.0) instead of sixteen
+        // 2-byte ones
+        const bool pk_a = (n == 16) && (((uint32_t)A + f0) & 1u) == 0;
+        const bool pk_c = (n == 16) && ((ag * (uint32_t)O + f0) & 1u) == 0;
+        uint32_t pr[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          if (q < n) {
-            const float v = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
-            *reinterpret_cast<_Float16*>(xa + 2 * (A + f0 + q)) = (_Float16)v;
-            if (SHARED) *reinterpret_cast<_Float16*>(xc + 2 * (f0 + q)) = (_Float16)v;
+        for (int q = 0; q < 16; q += 2) {
+          const uint32_t b0 = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 0x3C00u : 0u;  // f16 1.0 / 0.0
+          const uint32_t b1 = (((wds[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu) < 51u) ? 0x3C00u : 0u;
+          pr[q >> 1] = b0 | (b1 << 16);
+        }
+        if (pk_a) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) *reinterpret_cast<uint32_t*>(xa + 2 * (A + f0) + 4 * q) = pr[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (q < n) *reinterpret_cast<uint16_t*>(xa + 2 * (A + f0 + q)) = (uint16_t)(pr[q >> 1] >> (16 * (q & 1)));
           }
         }
-        if (c == 0) {
+        if (SHARED) {
+          if (pk_c) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<uint32_t*>(xc + 2 * f0 + 4 * q) = pr[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              if (q < n) *reinterpret_cast<uint16_t*>(xc + 2 * (f0 + q)) = (uint16_t)(pr[q >> 1] >> (16 * (q & 1)));
+            }
+          }
+        }
+      }
+      // the row's grid coordinates and the action mask of the new observation (a second Philox call per row): on the second
+      // wave of the critic group, idle in this phase - on the actor group's lanes with c == 0 every one of its waves ran it
+      if (!ACT_ROLE && tid >= 64 && tid < 128) {
+        const uint32_t row = (uint32_t)(tid - 64);
+        const uint32_t le = row / A, ag = row - le * A, e = e0 + le;
+        if ((int)e < E) {
+          const uint32_t ent = (a.env_offset + e) * A + ag;
+          u8* xa = lds + L.xa + (row >> 5) * 2 * xa_plane + (row & 31) * xa_row;
+          u8* xc = lds + L.xc + le * xc_row + 2 * (ag * O);
           const Philox4 cm = philox4x32_10(ent, tn, 0xFFFFu, ENV_STREAM, a.eseed_lo, a.eseed_hi);
           const float c0 = (float)(cm.x % 10u), c1 = (float)(cm.y % 10u);
           *reinterpret_cast<_Float16*>(xa + 2 * A) = (_Float16)c0;

@@ -96,6 +96,8 @@ int mava_clip_adam(float* p, const float* g, float* m, float* v, int32_t* count,
  * the block that finishes last.  workspace: mava_ppo_finish_workspace_bytes(Pa, Pc) bytes, 8-byte aligned, zeroed once by
  * the caller and owned by this call sequence afterwards. */
 size_t mava_ppo_finish_workspace_bytes(int Pa, int Pc);
+/* (n_slab = 0: `g` already holds the summed gradient and loss sums - the multi-rank path, whose all-reduce sits between the slab
+ * sums and Adam: only the Adam launch runs, norms from g, still carrying the count increment and the W1 re-split.) */
 int mava_ppo_finish_f32(mava_ctx* ctx, const float* slab_a, long stride_a, const float* slab_c, long stride_c, int n_slab,
                         int Pa, int Pc, float* g, float* p, float* m, float* v, int32_t* count, float lr_a, float lr_c,
                         float grad_scale, float max_norm, int decay, int steps_per_update, int num_updates, float b1,

@@ -382,9 +382,14 @@ extern "C" int mava_ppo_finish_f32(mava_ctx* ctx, const float* slab_a, long stri
                                    int num_updates, float b1, float b2, float eps, float vf_coef, float ent_coef,
                                    float* metrics_out, int critic_din, void* workspace, size_t workspace_bytes,
                                    hipStream_t s) {
-  MAVA_ARG_CHECK(Pa >= 1 && Pc >= 1 && n_slab >= 1 && stride_a >= Pa + 2 && stride_c >= Pc + 1, 0,
+  // n_slab == 0: `g` already holds [actor grad | critic grad | 3 loss sums] (summed over slabs, replicas and ranks by the
+  // caller - the multi-rank path, whose all-reduce sits between the slab sums and Adam): only the Adam launch runs, with the
+  // norms taken from g, and still carries the count increment and the W1 re-split (one launch instead of three)
+  const bool reduced = n_slab == 0;
+  MAVA_ARG_CHECK(Pa >= 1 && Pc >= 1 && n_slab >= 0 && (reduced || (stride_a >= Pa + 2 && stride_c >= Pc + 1)), 0,
                  "mava_ppo_finish_f32: Pa=%d Pc=%d n_slab=%d strides %ld %ld", Pa, Pc, n_slab, stride_a, stride_c);
-  MAVA_ARG_CHECK(slab_a && slab_c && g && p && m && v && count && workspace, 1, "mava_ppo_finish_f32: null pointer argument");
+  MAVA_ARG_CHECK((reduced || (slab_a && slab_c)) && g && p && m && v && count && workspace, 1,
+                 "mava_ppo_finish_f32: null pointer argument");
   MAVA_ARG_CHECK(workspace_bytes >= mava_ppo_finish_workspace_bytes(Pa, Pc) && ((uintptr_t)workspace & 7) == 0, 2,
                  "mava_ppo_finish_f32: workspace of %zu bytes (8-byte aligned, zeroed once) required",
                  mava_ppo_finish_workspace_bytes(Pa, Pc));
@@ -393,13 +398,15 @@ extern "C" int mava_ppo_finish_f32(mava_ctx* ctx, const float* slab_a, long stri
   const int nblk = finish_blocks(Pa, Pc);
   double* partials = static_cast<double*>(workspace);
   unsigned int* ticket = reinterpret_cast<unsigned int*>(partials + 2 * nblk);
-  hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3(nblk), dim3(256), 0, s, slab_a, stride_a, slab_c, stride_c, n_slab, Pa, Pc,
-                     grad_scale, g, partials);
-  MAVA_LAUNCH_CHECK();
+  if (!reduced) {
+    hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3(nblk), dim3(256), 0, s, slab_a, stride_a, slab_c, stride_c, n_slab, Pa, Pc,
+                       grad_scale, g, partials);
+    MAVA_LAUNCH_CHECK();
+  }
   AdamSegs segs = {};
   segs.off[0] = 0; segs.off[1] = Pa; segs.off[2] = Pa + Pc;
   segs.lr[0] = lr_a; segs.lr[1] = lr_c;
-  AdamTail tail = {partials, nblk, ticket, nullptr, 0, nullptr};
+  AdamTail tail = {reduced ? nullptr : partials, nblk, ticket, nullptr, 0, nullptr};
   // the wide f16x2 critic (96 .. 287 inputs) reads W1 through a pre-split copy: re-split it here, from the parameters this
   // launch writes, and mark the handle's copy fresh - the next critic launch of the handle then skips its own pack launch
   const int steps = (critic_din + 1 + 15) / 16;

@@ -211,6 +211,10 @@ class FFLearner:
         # (fixed order: replica 0's slabs, then replica 1's, ...; the mean over replicas of ff_mappo.py:232-238 is grad_scale).
         self.fused_tail = (self.world == 1 and not self.generic and os.environ.get("MAVA_FUSED_TAIL", "1") != "0")
         self._finish_ws = ops.ppo_finish_workspace(self.Pa, self.Pc, d) if self.fused_tail else None
+        # (several ranks: the slab sums stay separate launches around the split all-reduce; the Adam launch still carries the
+        # count increment and the W1 re-split: mava_ppo_finish_f32 with n_slab = 0)
+        self._finish_ws_mr = (ops.ppo_finish_workspace(self.Pa, self.Pc, d)
+                              if (not self.fused_tail and not self.generic and os.environ.get("MAVA_FUSED_TAIL", "1") != "0") else None)
         if self.fused_tail and self.U > 1:
             self.slab_a = torch.zeros((self.U * self.n_slab, self.Pa + 2), device=d)
             self.slab_c = torch.zeros((self.U * self.n_slab, self.Pc + 2), device=d)
@@ -489,6 +493,14 @@ class FFLearner:
         for wk in (w_actor, w_rest):
             if wk is not None:
                 wk.wait()
+        if self._finish_ws_mr is not None:  # several ranks: Adam + count increment + W1 re-split as one launch on the all-reduced g
+            self._timed("clip_adam", ops.ppo_finish, self.ctx, None, None, self.Pa, self.Pc, self.g, self.p, self.m, self.v, self.count,
+                        self.seg_lr[0], self.seg_lr[1], grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
+                        decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,
+                        num_updates=int(s.get("num_updates", 1) or 1), vf_coef=float(s.vf_coef), ent_coef=float(s.ent_coef),
+                        metrics_out=self.train_metrics[n, k, mb], critic_din=self.Oc, workspace=self._finish_ws_mr)
+            self.ent_step += 1
+            return
         self._timed("clip_adam", ops.clip_adam, self.p, self.g, self.m, self.v, self.count, self.seg_off, self.seg_lr,
                       grad_scale=1.0 / (self.U * self.world), max_norm=float(s.max_grad_norm),
                       decay=bool(s.decay_learning_rates), steps_per_update=self.K * self.M,

@@ -129,10 +129,12 @@ def ppo_finish(ctx: Optional[Ctx], slab_a, slab_c, Pa: int, Pc: int, g, p, m, v,
                eps: float = 1e-5) -> None:
     """Both slab reductions + clip + Adam + count increment (+ the wide critic's W1 re-split) in two launches
     (mava_ppo_finish_f32): the tail of a minibatch on one rank with one update-batch replica."""
-    _req(slab_a, torch.float32, "slab_a")
-    _req(slab_c, torch.float32, "slab_c")
-    if slab_a.dim() != 2 or slab_c.dim() != 2 or slab_a.shape[0] != slab_c.shape[0] or slab_a.shape[1] < Pa + 2 or slab_c.shape[1] < Pc + 1:
-        raise ValueError("ppo_finish: slabs must be (n_slab, >= P + 2) with equal slab counts")
+    reduced = slab_a is None  # g already holds the summed (all-reduced) gradient: the Adam launch alone (+ counts, W1 re-split)
+    if not reduced:
+        _req(slab_a, torch.float32, "slab_a")
+        _req(slab_c, torch.float32, "slab_c")
+        if slab_a.dim() != 2 or slab_c.dim() != 2 or slab_a.shape[0] != slab_c.shape[0] or slab_a.shape[1] < Pa + 2 or slab_c.shape[1] < Pc + 1:
+            raise ValueError("ppo_finish: slabs must be (n_slab, >= P + 2) with equal slab counts")
     for name, t, n in (("g", g, Pa + Pc + 3), ("p", p, Pa + Pc), ("m", m, Pa + Pc), ("v", v, Pa + Pc)):
         _req(t, torch.float32, name)
         if t.numel() < n:
@@ -141,7 +143,8 @@ def ppo_finish(ctx: Optional[Ctx], slab_a, slab_c, Pa: int, Pc: int, g, p, m, v,
     _req(workspace, torch.float64, "workspace")
     if metrics_out is not None:
         _req(metrics_out, torch.float32, "metrics_out")
-    check(lib().mava_ppo_finish_f32(ctx_ptr(ctx), ptr(slab_a), slab_a.shape[1], ptr(slab_c), slab_c.shape[1], slab_a.shape[0], Pa, Pc,
+    check(lib().mava_ppo_finish_f32(ctx_ptr(ctx), ptr(slab_a), 0 if reduced else slab_a.shape[1], ptr(slab_c),
+                                    0 if reduced else slab_c.shape[1], 0 if reduced else slab_a.shape[0], Pa, Pc,
                                     ptr(g), ptr(p), ptr(m), ptr(v), ptr(count), lr_a, lr_c, grad_scale, max_norm, int(decay),
                                     steps_per_update, num_updates, b1, b2, eps, vf_coef, ent_coef, ptr(metrics_out), critic_din,
                                     ptr(workspace), workspace.numel() * 8, stream_ptr()), "mava_ppo_finish_f32")

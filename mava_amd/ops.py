@@ -117,6 +117,16 @@ def slab_reduce(slab: torch.Tensor, n: int, out: torch.Tensor, accumulate: bool 
     )
 
 
+def slab_reduce_cols(slab: torch.Tensor, col0: int, n: int, out: torch.Tensor, accumulate: bool = False) -> None:
+    """out[:n] (+)= sum over slabs of columns [col0, col0 + n) - the same kernel on a column window, no copy of the window."""
+    _req(slab, torch.float32, "slab")
+    _req(out, torch.float32, "out")
+    if slab.dim() != 2 or col0 < 0 or slab.shape[1] < col0 + n or out.numel() < n:
+        raise ValueError("slab must be (n_slab, stride >= col0 + n) and out must hold n floats")
+    check(lib().mava_slab_reduce_f32(slab.data_ptr() + 4 * col0, slab.shape[0], slab.shape[1], n, int(accumulate), ptr(out), stream_ptr()),
+          "mava_slab_reduce_f32")
+
+
 def ppo_finish_workspace(Pa: int, Pc: int, device) -> torch.Tensor:
     """Zeroed workspace of ppo_finish (norm partials + arrival ticket); allocate once per learner."""
     n = int(lib().mava_ppo_finish_workspace_bytes(Pa, Pc))

@@ -201,6 +201,7 @@ class RecLearner:
         self.dscale_partials = torch.zeros((self.ws.loss_partials.shape[0], max(self.nA, 1)), device=d)
         self.seed = int(s.seed)
         self._t_range = torch.arange(self.T, device=d, dtype=torch.int64)[:, None] * self.E
+        self._t_range32 = self._t_range.to(torch.int32)
         self._learn_calls = 0  # guards.check_f16_range
 
     # ------------------------------------------------------------------------------------ setup
@@ -380,7 +381,7 @@ class RecLearner:
         T, E, A, Em, Rm = self.T, self.E, self.A, self.Em, self.Rm
         pa, pc = self.p[: self.Pa], self.p[self.Pa :]
         idx = perm[mb * Em : (mb + 1) * Em].contiguous()
-        flat_rows = (self._t_range + idx[None, :].long()).reshape(-1).to(torch.int32)  # (t*E + env) rows of the minibatch
+        flat_rows = (self._t_range32 + idx[None, :]).reshape(-1)  # (t*E + env) rows of the minibatch, int32 (T * E < 2^31): one launch
         L = lib()
         # f16x2: the output path (post_torso -> head -> loss -> backward) of both networks runs as ONE launch each
         # (mava_rec_out_f32); the continuous head and more than 16 actions stay on the layer-wise kernels

@@ -470,8 +470,8 @@ class _RecurrentNet:
             self.pre.backward(flat[: self.pre.num_params], wpre, [], grad_out[: self.pre.num_params], accumulate, grad_scale, d_feat=dfeat)
             return
         # transposed weights for the dX = dY W^T products (tiny, re-materialised per call)
-        WheadT = self.seg(flat, "Whead").t().contiguous()
-        WpostT = self.seg(flat, "Wpost").t().contiguous()
+        WheadT = None if from_scan else self.seg(flat, "Whead").t().contiguous()  # (the fused output path needs neither)
+        WpostT = None if from_scan else self.seg(flat, "Wpost").t().contiguous()
         WiT = self.seg(flat, "Wi").t().contiguous()
         d = lambda k, N, x, w, ldw, gate, y: launch(
             "rec_dense(bwd)", L.mava_rec_dense_f32, ctx_ptr(self.ctx), ptr(x), 0, None, 0, 0, 0, 1, k, 0, ptr(w), ldw, None, ptr(gate), ptr(y), 0, k, N,
@@ -488,10 +488,12 @@ class _RecurrentNet:
             Y's features from y_split on are those of y_tail (T32, N - y_split features per tile) when given"""
             launch("rec_xty", L.mava_rec_xty_f32, ctx_ptr(self.ctx), x_ptr, x_rowmajor, ptr(idx) if x_rowmajor else None, Rm, E, A, xs, x_ld, ptr(y), 0,
                    ptr(y_tail), y_split, N - y_split, K, N, rows, 1, 1.0 / grad_scale, ptr(slabs), slabs.shape[1], slabs.shape[0], s)
-            ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
-            if b_off is not None:
-                tail = slabs[:, K * N + bias_slice : K * N + bias_slice + nb].contiguous()
-                ops.slab_reduce(tail, nb, grad_out[b_off : b_off + nb], accumulate=accumulate)
+            if b_off is not None and bias_slice == 0:  # weights and the adjacent bias sums in one launch
+                ops.slab_reduce2(slabs, K * N, grad_out[w_off : w_off + K * N], nb, grad_out[b_off : b_off + nb], accumulate=accumulate)
+            else:
+                ops.slab_reduce(slabs, K * N, grad_out[w_off : w_off + K * N], accumulate=accumulate)
+                if b_off is not None:  # a window of the column sums (db_hn: the n third), summed where it lies
+                    ops.slab_reduce_cols(slabs, K * N + bias_slice, nb, grad_out[b_off : b_off + nb], accumulate=accumulate)
 
         o = lambda n: self.off[n][0]
         if not from_scan:

@@ -362,7 +362,13 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   const int trow = 8 * kg + tq;                       // transposed reads: block row of the first 4-row block
   const int trb = WROW * trow + 8 * (tp & 1);         // (second block: 4 rows = 1024 bytes on; same swizzle)
   const int thx = 16 * ((tp >> 1) ^ w8_sw(trow));     // chunk 2 t + (tp >> 1) of column tile t: ((32 t) ^ thx)
-  auto tr_addr = [&](int t) -> int { return trb + ((32 * t) ^ thx); };
+  int trA[8];  // tile-invariant: kept in registers (an xor + add per use otherwise: ~30 vector instructions per tile)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    trA[t] = trb + ((32 * t) ^ thx);
+    asm volatile("" : "+v"(trA[t]));
+  }
+  auto tr_addr = [&](int t) -> int { return trA[t]; };
   const int trOwn = tr_addr(v);                       // this wave's own 16 columns
   auto read_tr = [&](const u8* img, int plane, int a0) -> Frag {
     Frag f;

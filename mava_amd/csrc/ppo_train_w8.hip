@@ -118,9 +118,9 @@ inline W8Layout make_w8_layout() {
 
 // NO: padded action count of the loss lanes (8 or 16); S1: 32-input steps of layer 1 (din + 1 <= 32 S1 <= 128);
 // XV: floats per staged piece (2 when the rows are 8-byte aligned and din is even).
-// W2RES: the layer-2 forward operand (this wave's 16 columns of W2: 32 registers) stays in registers; otherwise it is read
-// from the W2 image with hardware-transposed reads (16 per tile and wave) - the default: with it resident the kernel
-// needs 271 registers and spills inside the tile loop.
+// W2R: steps (of four) of the layer-2 forward operand - this wave's 16 columns of W2, 8 registers a step - that stay in
+// registers; the others are read from the W2 image with hardware-transposed reads (4 per step, tile and wave).  All four
+// resident need 271 registers and spill inside the tile loop; w8_w2r() below picks two where they fit.
 // ROLE: with 8 action lanes per row the loss occupies 256 threads, so the per-row duties are divided between the two wave
 // groups (separate functions: separate register sets): ROLE 1 = waves 0-3, the loss of the tile's 32 rows; ROLE 2 = waves 4-7,
 // the x staging (gather of the next tile's rows, split + commit into the other x buffer) - in the first version, where
@@ -128,7 +128,7 @@ inline W8Layout make_w8_layout() {
 // (phase stamps).  ROLE 0 (16 action lanes: every thread is a loss lane) does both.  All roles run the same barrier sequence
 // and the same matrix work on their own 16 features.  (A static priority raise for waves 4-7, the younger half that loses
 // issue arbitration against its SIMD partners - s_setprio 1 - was measured: 65.5 M env-steps/s either way.)
-template <int NO, int S1, int XV, bool W2RES, int ROLE>
+template <int NO, int S1, int XV, int W2R, int ROLE>
 __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, u8* lds) {
   constexpr bool DO_LOSS = ROLE != 2, DO_STAGE = ROLE != 1;
   constexpr int KT1 = 2 * S1;  // 16-input tiles of the layer-1 weight gradient
@@ -188,7 +188,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   }
   // ---------------------------------------------------------------- weight fragments kept in registers
   // layer 1 (A operand): W1[k = 32 s + 8 kg + e][f = 16 v + i]; k == din is b1, k > din zero
-  Frag W1f[S1], W2f[W2RES ? 4 : 1];
+  Frag W1f[S1], W2f[W2R > 0 ? W2R : 1];
   {
     float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
@@ -202,7 +202,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
       W1f[s] = split8_carry(w, c1);
     }
 #pragma unroll
-    for (int s = 0; s < (W2RES ? 4 : 0); ++s) {  // layer 2 (A operand): W2[k = 32 s + 8 kg + e][n = 16 v + i]
+    for (int s = 0; s < W2R; ++s) {  // layer 2 (A operand), the first W2R steps: W2[k = 32 s + 8 kg + e][n = 16 v + i]
       float w[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) w[e] = P[oW2 + (32 * s + 8 * kg + e) * MLP_H + 16 * v + i];
@@ -468,15 +468,15 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) hb[nt] = read_row(H1I + 4096 * nt, WPLANE32, rdA[0]);
       // (not resident: W2[k = 32 s + 8 kg + e][n = 16 v + i] = rows 32 s + 8 kg .. of this wave's column tile of the W2 image)
-      if constexpr (!W2RES) wn = read_tr(W2I, W2PLANE, trOwn);
+      if constexpr (W2R < 1) wn = read_tr(W2I, W2PLANE, trOwn);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         Frag b[2] = {hb[0], hb[1]};
-        const Frag a = W2RES ? W2f[W2RES ? s : 0] : wn;
+        const Frag a = (s < W2R) ? W2f[s < W2R ? s : 0] : wn;
         if (s + 1 < 4) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) hb[nt] = read_row(H1I + 4096 * nt, WPLANE32, rdA[s + 1]);
-          if constexpr (!W2RES) wn = read_tr(W2I + 32 * (s + 1) * WROW, W2PLANE, trOwn);
+          if (s + 1 >= W2R) wn = read_tr(W2I + 32 * (s + 1) * WROW, W2PLANE, trOwn);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) h2[nt] = mfma3w(a, b[nt], h2[nt]);
@@ -732,20 +732,26 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   }
 }
 
-#ifndef MAVA_W8_W2RES
-#define MAVA_W8_W2RES false
+// Steps of the layer-2 forward operand kept in registers, per instantiation: two of the four where the register file has room
+// (kernel-resource remarks: 254 of 256 registers at <8, 3, 2>, no spills), none in the wide instantiations
+constexpr int w8_w2r(int no, int s1, int xv) {
+#ifdef MAVA_W8_W2R
+  return MAVA_W8_W2R;
+#else
+  return (no == 8) ? ((s1 <= 2) ? 2 : ((s1 == 3 && xv == 2) ? 2 : 0)) : ((s1 <= 2) ? 2 : 0);
 #endif
-template <int NO, int S1, int XV, bool W2RES>
+}
+template <int NO, int S1, int XV, int W2R>
 __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8Layout L) {
   extern __shared__ __attribute__((aligned(16))) u8 lds[];
   if constexpr (NO == 8) {
     if (threadIdx.x < 256) {
-      w8_body<NO, S1, XV, W2RES, 1>(tk, L, lds);
+      w8_body<NO, S1, XV, W2R, 1>(tk, L, lds);
     } else {
-      w8_body<NO, S1, XV, W2RES, 2>(tk, L, lds);
+      w8_body<NO, S1, XV, W2R, 2>(tk, L, lds);
     }
   } else {
-    w8_body<NO, S1, XV, W2RES, 0>(tk, L, lds);
+    w8_body<NO, S1, XV, W2R, 0>(tk, L, lds);
   }
 }
 
@@ -754,11 +760,11 @@ int launch_w8(const TrainTask& tk, int n_slab, hipStream_t s) {
   const W8Layout L = make_w8_layout();
   static bool attr_set = false;
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_w8_kernel<NO, S1, XV, MAVA_W8_W2RES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV)>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        L.end));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_train_w8_kernel<NO, S1, XV, MAVA_W8_W2RES>), dim3(n_slab), dim3(512), L.end, s, tk, L);
+  hipLaunchKernelGGL((ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV)>), dim3(n_slab), dim3(512), L.end, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
@@ -766,7 +772,10 @@ int launch_w8(const TrainTask& tk, int n_slab, hipStream_t s) {
 template <int NO, int S1>
 int dispatch_w8_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
   if (tk.din % 2 == 0 && ((uintptr_t)tk.x) % 8 == 0) return launch_w8<NO, S1, 2>(tk, n_slab, s);
-  return launch_w8<NO, S1, 1>(tk, n_slab, s);
+  // (97 .. 127 inputs staged one float at a time need more staging registers than the eight-wave kernel has: hundreds of
+  // spilled registers - the four-wave kernel takes that shape)
+  if constexpr (S1 == 4) return 1;
+  else return launch_w8<NO, S1, 1>(tk, n_slab, s);
 }
 
 template <int NO>

@@ -1093,8 +1093,8 @@ static int h2_dispatch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool acto
 int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk_in, int n_slab, bool actor, hipStream_t s) {
   TrainTask tk = tk_in;
   tk.force_xlo = (ctx->train_variant & 2) != 0;
-  if (actor && (ctx->train_variant & 1) == 0) {
-    const int rc8 = mava_train_w8_launch(tk, n_slab, s);
+  if ((ctx->train_variant & 1) == 0) {  // the eight-wave kernel: the discrete actor and the value network on narrow inputs
+    const int rc8 = mava_train_w8_launch(tk, n_slab, actor, s);
     if (rc8 <= 0) {
       if (rc8 == 0) { ++ctx->h2_launches; ++ctx->w8_launches; }
       return rc8;

@@ -38,5 +38,5 @@ struct TrainTask {
 struct mava_ctx;
 // ppo_train_w8.hip: the discrete actor's kernel on eight waves (two per SIMD, 16 features per wave, 16x16x32 MFMAs); same
 // return convention.  Tried first by mava_train_h2_launch unless the handle's MAVA_CTX_TRAIN_VARIANT is 1.
-int mava_train_w8_launch(const TrainTask& tk, int n_slab, hipStream_t s);
+int mava_train_w8_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s);
 int mava_train_h2_launch(mava_ctx* ctx, const TrainTask& tk, int n_slab, bool actor, hipStream_t s);

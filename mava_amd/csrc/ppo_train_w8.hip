@@ -128,9 +128,13 @@ inline W8Layout make_w8_layout() {
 // (phase stamps).  ROLE 0 (16 action lanes: every thread is a loss lane) does both.  All roles run the same barrier sequence
 // and the same matrix work on their own 16 features.  (A static priority raise for waves 4-7, the younger half that loses
 // issue arbitration against its SIMD partners - s_setprio 1 - was measured: 65.5 M env-steps/s either way.)
-template <int NO, int S1, int XV, int W2R, int ROLE>
+template <int NO, int S1, int XV, int W2R, bool ACTOR, int ROLE>
 __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, u8* lds) {
   constexpr bool DO_LOSS = ROLE != 2, DO_STAGE = ROLE != 1;
+  // ACTOR = false: the value network on narrow inputs (ff_ippo's critic, ff_mappo.py:183-213): one output, the clipped value
+  // loss on lane 0 of a row's NO loss lanes; its weights are split as WS * w and the layer accumulators unscaled by WU
+  // (h2_core.h W_SCALE_CRITIC: the low terms of the weights leave f16's subnormal range)
+  constexpr float WS = ACTOR ? 1.0f : W_SCALE_CRITIC, WU = 1.0f / WS;
   constexpr int KT1 = 2 * S1;  // 16-input tiles of the layer-1 weight gradient
   u8* const H1I = lds + L.h1;
   u8* const DZ2I = lds + L.dz2;
@@ -170,13 +174,13 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 #pragma unroll 8
     for (int k = k0; k < k0 + 32; ++k) {
       _Float16 x0, x1;
-      split1_carry(P[oW2 + k * MLP_H + n], carry, x0, x1);
+      split1_carry(P[oW2 + k * MLP_H + n] * WS, carry, x0, x1);
       const int o = w8_off(k, n >> 3) + 2 * (n & 7);
       *reinterpret_cast<_Float16*>(W2I + o) = x0;
       *reinterpret_cast<_Float16*>(W2I + W2PLANE + o) = x1;
     }
   }
-  if (tid == 0) {
+  if (ACTOR && tid == 0) {
     // ff_mappo.py:164  gae = (gae - gae.mean()) / (gae.std() + 1e-8)   (population std)
     double s1 = 0.0, s2 = 0.0;
     for (int b = 0; b < STATS_BLOCKS; ++b) { s1 += tk.stats[2 * b]; s2 += tk.stats[2 * b + 1]; }
@@ -197,7 +201,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 32 * s + 8 * kg + e;
-        w[e] = (k <= din) ? P[k * MLP_H + 16 * v + i] : 0.0f;
+        w[e] = (k <= din) ? P[k * MLP_H + 16 * v + i] * WS : 0.0f;
       }
       W1f[s] = split8_carry(w, c1);
     }
@@ -205,7 +209,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     for (int s = 0; s < W2R; ++s) {  // layer 2 (A operand), the first W2R steps: W2[k = 32 s + 8 kg + e][n = 16 v + i]
       float w[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] = P[oW2 + (32 * s + 8 * kg + e) * MLP_H + 16 * v + i];
+      for (int e = 0; e < 8; ++e) w[e] = P[oW2 + (32 * s + 8 * kg + e) * MLP_H + 16 * v + i] * WS;
       W2f[s] = split8_carry(w, c2);
     }
   }
@@ -222,9 +226,9 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   }
   float b2r[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) b2r[r] = P[mlp_off_b2(din) + 16 * v + 4 * kg + r];
+  for (int r = 0; r < 4; ++r) b2r[r] = P[mlp_off_b2(din) + 16 * v + 4 * kg + r] * WS;  // (unscaled with the products)
   __syncthreads();
-  const float adv_mean = misc[0], adv_rstd = misc[1];
+  const float adv_mean = ACTOR ? misc[0] : 0.0f, adv_rstd = ACTOR ? misc[1] : 0.0f;
 
   // persistent accumulators (R x gradient units): wave v owns output columns [16 v, 16 v + 16) of dW1 and dW2
   f32x4 gW1[KT1], gW2[8], gW3;
@@ -268,6 +272,12 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     const uint32_t b = in ? c.b : b_last;
     a_out = in ? c.a : a_last;
     p_raw = tk.idx ? tk.idx[b] : (int32_t)(tk.idx_base + (long)b);
+  };
+  // input row of agent row (index p, agent a): the critic's inputs may be shared by groups of xshare agent rows
+  auto stage_row = [&](int32_t p_raw, uint32_t a) -> uint32_t {
+    const uint32_t fr = (uint32_t)p_raw * Au + a;
+    if constexpr (ACTOR) return fr;
+    else return (tk.xshare == 1) ? fr : ((uint32_t)tk.xshare == Au ? (uint32_t)p_raw : fr / (uint32_t)tk.xshare);
   };
   auto stage_issue = [&](uint32_t fr, float (&xr)[NR]) {
     const float* xrow = tk.x + (long)fr * din;
@@ -314,12 +324,19 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     if (lo_any != 0) xflag[buf] = 1u;  // (every writer stores the same value)
   };
   auto load_row = [&](uint32_t fr, int& act, float& f0, float& f1, uint32_t& m) {
-    act = tk.action[fr];
-    f0 = tk.old_logp[fr];
-    f1 = tk.adv[fr];
-    const uint8_t* mk = (tk.mask != nullptr && lo < no) ? (tk.mask + (long)fr * no + lo) : nullptr;
-    m = 1u;
-    if (mk != nullptr) m = *mk;
+    if constexpr (ACTOR) {
+      act = tk.action[fr];
+      f0 = tk.old_logp[fr];
+      f1 = tk.adv[fr];
+      const uint8_t* mk = (tk.mask != nullptr && lo < no) ? (tk.mask + (long)fr * no + lo) : nullptr;
+      m = 1u;
+      if (mk != nullptr) m = *mk;
+    } else {
+      act = 0;
+      f0 = tk.old_value[fr];
+      f1 = tk.targets[fr];
+      m = 0u;
+    }
   };
 
   const long ntiles = (R + 31) / 32;
@@ -334,7 +351,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
   if (it < ntiles) {
     if constexpr (DO_STAGE) {
       cursor_gather(cs, ps_next, as_next);
-      stage_issue((uint32_t)ps_next * Au + as_next, xr);
+      stage_issue(stage_row(ps_next, as_next), xr);
     }
     if constexpr (DO_LOSS) {
       cursor_gather(cl, pl_next, al_next);
@@ -389,7 +406,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     const bool have_next = itn < ntiles;
     const u8* const XSI = lds + L.xs + buf * WIMG;
     // rows of the next tile from the indices loaded a tile ago
-    uint32_t xrow_next = DO_STAGE ? ((uint32_t)ps_next * Au + as_next) : 0u, lrow_next = DO_LOSS ? ((uint32_t)pl_next * Au + al_next) : 0u;
+    uint32_t xrow_next = DO_STAGE ? stage_row(ps_next, as_next) : 0u, lrow_next = DO_LOSS ? ((uint32_t)pl_next * Au + al_next) : 0u;
     if constexpr (DO_STAGE) asm volatile("" : "+v"(xrow_next));
     if constexpr (DO_LOSS) asm volatile("" : "+v"(lrow_next));
 
@@ -433,7 +450,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[nt][r] = fmaxf(acc[nt][r], 0.0f);
+        acc[nt][r] = fmaxf(ACTOR ? acc[nt][r] : acc[nt][r] * WU, 0.0f);
         relu1 |= (acc[nt][r] > 0.0f) ? (1u << (4 * nt + r)) : 0u;
       }
       const Frag4 f = split4(acc[nt]);
@@ -489,7 +506,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        h2[nt][r] = fmaxf(h2[nt][r], 0.0f);
+        h2[nt][r] = fmaxf(ACTOR ? h2[nt][r] : h2[nt][r] * WU, 0.0f);
         relu2 |= (h2[nt][r] > 0.0f) ? (1u << (4 * nt + r)) : 0u;
       }
       const Frag4 f = split4(h2[nt]);
@@ -516,40 +533,57 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
       float y = B3s[lo];
 #pragma unroll
       for (int u = 0; u < 8; ++u) y += yp[u * 32 * YSTR];
-      // masked Categorical over the NO lanes of the row (networks.py:116-124, distributions.py:146-165)
-      const bool legal = (lo < no) && (r_m != 0u);
-      const float z = legal ? y : -FLT_MAX;
-      auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
-      auto add_op = [](float a, float b) { return a + b; };
-      const float mx = group_allreduce<NO>(z, fmax_op);
-      const float se = group_allreduce<NO>(expf(z - mx), add_op);
-      const float logp = z - (mx + logf(se));
-      const float pr = expf(logp);
-      const float ent = group_allreduce<NO>((pr > 0.0f) ? -(pr * logp) : 0.0f, add_op);
-      const int act = r_act;
-      const float lp = group_allreduce<NO>((lo == act) ? logp : 0.0f, add_op);
-      const float gae = (r_f1 - adv_mean) * adv_rstd;
-      const float ratio = expf(lp - r_f0);
-      const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
-      const float l1 = ratio * gae, l2 = rc * gae;
-      const float pg = -fminf(l1, l2);
-      const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
-      const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-      const float g2 = inside ? (1.0f - g1) : 0.0f;
-      const float dlp = rvalid ? (-(g1 + g2) * gae * ratio) : 0.0f;  // x R: the 1/R of .mean() is applied at the end
-      const float ec = rvalid ? tk.ent_coef : 0.0f;
-      const float oh = (lo == act) ? 1.0f : 0.0f;
-      const float pl2 = (pr > 0.0f) ? logp : 0.0f;
-      float dyo = dlp * (oh - pr) + ec * pr * (pl2 + ent);
-      if (z == -FLT_MAX) dyo = 0.0f;
+      float dyo = 0.0f, pg_row = 0.0f, ent_row = 0.0f;
+      if constexpr (ACTOR) {
+        // masked Categorical over the NO lanes of the row (networks.py:116-124, distributions.py:146-165)
+        const bool legal = (lo < no) && (r_m != 0u);
+        const float z = legal ? y : -FLT_MAX;
+        auto fmax_op = [](float a, float b) { return fmaxf(a, b); };
+        auto add_op = [](float a, float b) { return a + b; };
+        const float mx = group_allreduce<NO>(z, fmax_op);
+        const float se = group_allreduce<NO>(expf(z - mx), add_op);
+        const float logp = z - (mx + logf(se));
+        const float pr = expf(logp);
+        const float ent = group_allreduce<NO>((pr > 0.0f) ? -(pr * logp) : 0.0f, add_op);
+        const int act = r_act;
+        const float lp = group_allreduce<NO>((lo == act) ? logp : 0.0f, add_op);
+        const float gae = (r_f1 - adv_mean) * adv_rstd;
+        const float ratio = expf(lp - r_f0);
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+        const float l1 = ratio * gae, l2 = rc * gae;
+        const float pg = -fminf(l1, l2);
+        const bool inside = (ratio >= lo_c) && (ratio <= hi_c);
+        const float g1 = (l1 < l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+        const float g2 = inside ? (1.0f - g1) : 0.0f;
+        const float dlp = rvalid ? (-(g1 + g2) * gae * ratio) : 0.0f;  // x R: the 1/R of .mean() is applied at the end
+        const float ec = rvalid ? tk.ent_coef : 0.0f;
+        const float oh = (lo == act) ? 1.0f : 0.0f;
+        const float pl2 = (pr > 0.0f) ? logp : 0.0f;
+        dyo = dlp * (oh - pr) + ec * pr * (pl2 + ent);
+        if (z == -FLT_MAX) dyo = 0.0f;
+        pg_row = pg;
+        ent_row = ent;
+      } else {
+        // clipped value loss (ff_mappo.py:198-213) on lane 0 of the row: y is the value
+        const float ov = r_f0, tg = r_f1;
+        const float diff = y - ov;
+        const float vclip = ov + fminf(fmaxf(diff, -tk.clip_eps), tk.clip_eps);
+        const float e1 = y - tg, e2 = vclip - tg;
+        const float l1 = e1 * e1, l2 = e2 * e2;
+        const bool inside = (diff >= -tk.clip_eps) && (diff <= tk.clip_eps);
+        const float g1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
+        const float g2 = inside ? (1.0f - g1) : 0.0f;
+        dyo = (rvalid && lo == 0) ? (tk.vf_coef * (g1 * e1 + g2 * e2)) : 0.0f;  // x R
+        pg_row = 0.5f * fmaxf(l1, l2);
+      }
       _Float16 da, db;
       split1(dyo, da, db);
       *reinterpret_cast<_Float16*>(DYI + lrow * DYROW + 2 * lo) = da;
       *reinterpret_cast<_Float16*>(DYI + DYPLANE + lrow * DYROW + 2 * lo) = db;
       ab3 += dyo;
       if (rvalid && lo == 0) {
-        loss_a += pg * invR;
-        loss_b += ent * invR;
+        loss_a += pg_row * invR;
+        loss_b += ent_row * invR;
       }
       r_act = n_act; r_f0 = n_f0; r_f1 = n_f1; r_m = n_m;
     }
@@ -633,7 +667,7 @@ __device__ __forceinline__ void w8_body(const TrainTask& tk, const W8Layout& L, 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[nt][r] = ((relu1 >> (4 * nt + r)) & 1u) ? acc[nt][r] : 0.0f;
+        for (int r = 0; r < 4; ++r) acc[nt][r] = ((relu1 >> (4 * nt + r)) & 1u) ? (ACTOR ? acc[nt][r] : acc[nt][r] * WU) : 0.0f;
         const Frag4 f = split4(acc[nt]);
         *reinterpret_cast<half4*>(DZ1I + 4096 * nt + wrA) = f.hi;
         *reinterpret_cast<half4*>(DZ1I + 4096 * nt + WPLANE32 + wrA) = f.lo;
@@ -741,66 +775,70 @@ constexpr int w8_w2r(int no, int s1, int xv) {
   return (no == 8) ? ((s1 <= 2) ? 2 : ((s1 == 3 && xv == 2) ? 2 : 0)) : ((s1 <= 2) ? 2 : 0);
 #endif
 }
-template <int NO, int S1, int XV, int W2R>
+template <int NO, int S1, int XV, int W2R, bool ACTOR>
 __global__ __launch_bounds__(512, 2) void ppo_train_w8_kernel(TrainTask tk, W8Layout L) {
   extern __shared__ __attribute__((aligned(16))) u8 lds[];
   if constexpr (NO == 8) {
     if (threadIdx.x < 256) {
-      w8_body<NO, S1, XV, W2R, 1>(tk, L, lds);
+      w8_body<NO, S1, XV, W2R, ACTOR, 1>(tk, L, lds);
     } else {
-      w8_body<NO, S1, XV, W2R, 2>(tk, L, lds);
+      w8_body<NO, S1, XV, W2R, ACTOR, 2>(tk, L, lds);
     }
   } else {
-    w8_body<NO, S1, XV, W2R, 0>(tk, L, lds);
+    w8_body<NO, S1, XV, W2R, ACTOR, 0>(tk, L, lds);
   }
 }
 
-template <int NO, int S1, int XV>
+template <int NO, int S1, int XV, bool ACTOR>
 int launch_w8(const TrainTask& tk, int n_slab, hipStream_t s) {
   const W8Layout L = make_w8_layout();
   static bool attr_set = false;
   if (!attr_set) {
-    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV)>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MAVA_HIP_CHECK(hipFuncSetAttribute((const void*)ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV), ACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        L.end));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV)>), dim3(n_slab), dim3(512), L.end, s, tk, L);
+  hipLaunchKernelGGL((ppo_train_w8_kernel<NO, S1, XV, w8_w2r(NO, S1, XV), ACTOR>), dim3(n_slab), dim3(512), L.end, s, tk, L);
   MAVA_LAUNCH_CHECK();
   return MAVA_OK;
 }
 
-template <int NO, int S1>
+template <int NO, int S1, bool ACTOR>
 int dispatch_w8_xv(const TrainTask& tk, int n_slab, hipStream_t s) {
-  if (tk.din % 2 == 0 && ((uintptr_t)tk.x) % 8 == 0) return launch_w8<NO, S1, 2>(tk, n_slab, s);
+  if (tk.din % 2 == 0 && ((uintptr_t)tk.x) % 8 == 0) return launch_w8<NO, S1, 2, ACTOR>(tk, n_slab, s);
   // (97 .. 127 inputs staged one float at a time need more staging registers than the eight-wave kernel has: hundreds of
   // spilled registers - the four-wave kernel takes that shape)
   if constexpr (S1 == 4) return 1;
-  else return launch_w8<NO, S1, 1>(tk, n_slab, s);
+  else return launch_w8<NO, S1, 1, ACTOR>(tk, n_slab, s);
 }
 
-template <int NO>
+template <int NO, bool ACTOR>
 int dispatch_w8(const TrainTask& tk, int n_slab, hipStream_t s) {
   const int s1 = (tk.din + 1 + 31) / 32;  // 32-input steps of layer 1, including the ones (bias) column
   switch (s1) {
 #ifndef MAVA_FAST_BUILD
-    case 1: return dispatch_w8_xv<NO, 1>(tk, n_slab, s);
-    case 2: return dispatch_w8_xv<NO, 2>(tk, n_slab, s);
-    case 4: return dispatch_w8_xv<NO, 4>(tk, n_slab, s);
+    case 1: return dispatch_w8_xv<NO, 1, ACTOR>(tk, n_slab, s);
+    case 2: return dispatch_w8_xv<NO, 2, ACTOR>(tk, n_slab, s);
+    case 4: return dispatch_w8_xv<NO, 4, ACTOR>(tk, n_slab, s);
 #endif
-    case 3: return dispatch_w8_xv<NO, 3>(tk, n_slab, s);
+    case 3: return dispatch_w8_xv<NO, 3, ACTOR>(tk, n_slab, s);
     default: return 1;
   }
 }
 
 }  // namespace
 
-// Discrete actor, input width <= 127, <= 16 actions.  Returns MAVA_OK, 1 when the shape is not instantiated here (the
-// caller then runs ppo_train_h2.hip's four-wave kernel), or a negative error code.
-int mava_train_w8_launch(const TrainTask& tk, int n_slab, hipStream_t s) {
+// Discrete actor (<= 16 actions) or the value network without input aggregation, input width <= 127.  Returns MAVA_OK, 1 when
+// the shape is not instantiated here (the caller then runs ppo_train_h2.hip's four-wave kernels), or a negative error code.
+int mava_train_w8_launch(const TrainTask& tk, int n_slab, bool actor, hipStream_t s) {
   if (tk.action_f != nullptr || tk.din + 1 > 128) return 1;
-  if (tk.no <= 8) return dispatch_w8<8>(tk, n_slab, s);
+  if (!actor) {
+    if (tk.agg > 1 || tk.no != 1) return 1;
+    return dispatch_w8<8, false>(tk, n_slab, s);
+  }
+  if (tk.no <= 8) return dispatch_w8<8, true>(tk, n_slab, s);
 #ifndef MAVA_FAST_BUILD
-  if (tk.no <= 16) return dispatch_w8<16>(tk, n_slab, s);
+  if (tk.no <= 16) return dispatch_w8<16, true>(tk, n_slab, s);
 #endif
   return 1;
 }

@@ -375,8 +375,6 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
 
     if agg == 0 and not shared:
         pytest.skip("aggregation only applies to shared critic inputs")
-    if matmul_mode[2].get(matmul_mode[2].TRAIN_VARIANT) == 1:
-        pytest.skip("the kernel variant only concerns the actor")
     matmul_mode[2].set(matmul_mode[2].CRITIC_AGGREGATION, agg)
 
     rng = np.random.default_rng(TE + O)
@@ -411,6 +409,12 @@ def test_critic_grad_matches_oracle(dev, TE, A, O, Rb, use_idx, shared, n_slab, 
     assert_close(got[P:P + 1], np.array([vl]), 1e-5, "value loss", scale=1.0)
     if matmul_mode[0] == 1:  # input widths up to 287 run on the f16x2 kernel (> 95: streamed W1), wider ones fall back
         assert matmul_mode[1]() == (1 if din <= 287 else 0)
+        # the eight-wave kernel serves the value network on inputs up to 127 wide when no agents are aggregated into a row
+        # (ff_ippo's critic); the four-wave kernels take the rest (and everything under MAVA_CTX_TRAIN_VARIANT bit 0)
+        ctx = matmul_mode[2]
+        aggregated = agg == 1 and shared and A > 1
+        want_w8 = ctx.get(ctx.TRAIN_VARIANT) == 0 and din + 1 <= 128 and not aggregated
+        assert ctx.get(ctx.W8_LAUNCHES) == (1 if want_w8 else 0), "eight-wave / four-wave kernel selection (critic)"
 
 
 def test_train_kernels_full_launch_shape(dev, matmul_mode):

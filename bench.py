@@ -271,11 +271,13 @@ def ff_rooflines(L, matmul: str, timers: dict, timer_steps: int, default_shape: 
     peak_c = F16X2_PEAK_TFLOPS if h2_c else F32_MFMA_PEAK_TFLOPS
     # the discrete actor up to 127 inputs / 16 actions runs on the eight-wave kernel (ppo_train_w8.hip) unless the handle's
     # MAVA_CTX_TRAIN_VARIANT is 1
-    w8_a = h2_a and L.Oa + 1 <= 128 and L.nA <= 16 and L.ctx.get(L.ctx.TRAIN_VARIANT) == 0
+    w8_a = h2_a and L.Oa + 1 <= 128 and L.nA <= 16 and (L.ctx.get(L.ctx.TRAIN_VARIANT) & 1) == 0
+    # ... and so does the value network on inputs up to 127 wide when no agents are aggregated into a row (ff_ippo's critic)
+    w8_c = h2_c and L.Oc + 1 <= 128 and not aggregated and (L.ctx.get(L.ctx.TRAIN_VARIANT) & 1) == 0
 
     def kname(h2, net):
-        if net == "actor" and w8_a:
-            return "ppo_train_w8_kernel<actor> (fused fwd+loss+bwd+dW, eight waves, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
+        if (net == "actor" and w8_a) or (net == "critic" and w8_c):
+            return f"ppo_train_w8_kernel<{net}> (fused fwd+loss+bwd+dW, eight waves, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
         if h2:
             return f"ppo_train_h2_kernel<{net}> (fused fwd+loss+bwd+dW, 3 f16 MFMAs per product; peak = dense f16 peak / 3)"
         return f"ppo_train_kernel<{net}> (fused fwd+loss+bwd+dW, exact-f32 MFMA)"
@@ -283,6 +285,8 @@ def ff_rooflines(L, matmul: str, timers: dict, timer_steps: int, default_shape: 
     def tkey(h2, net):
         if net == "actor" and w8_a:
             return next((k for k in traffic if k.startswith("ppo_train_w8_kernel")), None)
+        if net == "critic" and w8_c:
+            return None  # (no committed counter pass for this secondary shape)
         return next((k for k in traffic if k.startswith("ppo_train_h2_kernel" if h2 else "ppo_train_kernel")
                      and (("true" in k.split(",")[2]) == (net == "actor") if h2 else net in k)), None)
     roof_c = {"kernel": kname(h2_c, "critic") + (", agents of a row aggregated" if aggregated else ""),

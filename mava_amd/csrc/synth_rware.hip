@@ -61,18 +61,23 @@ struct SynthArgs {
 // writes the row's one-hot id and its two grid coordinates.  A thread per output float - the first version -
 // recomputed the same Philox block 16 times and was VALU-bound at 13 us per step.  Then one thread per
 // (env, agent) for the small per-agent / per-env data.
-__device__ __forceinline__ void store_run(float* dst, const float (&v)[16], int n, bool vec2) {
-  if (vec2 && n == 16) {
+// The chunks of a wave leave as 16 store instructions, each writing 4 chunks x 16 consecutive floats (a full 64-byte run per
+// 16 lanes): the lane that DREW a chunk stored it with 8 eight-byte stores whose 64 lanes were 64 bytes apart - every
+// instruction touched 64 cache lines, and the kernel took 17 us per step at the SMAX shape for 10 MB.  The values cross the
+// lanes through a wave-private LDS tile ([lane][17]: conflict-free both ways); n = 0 for a lane without a chunk.
+__device__ __forceinline__ void wave_store_chunks(float* base, long off, int n, const float* tile, int lane) {
 #pragma unroll
-    for (int q = 0; q < 16; q += 2) *reinterpret_cast<float2*>(dst + q) = make_float2(v[q], v[q + 1]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      if (q < n) dst[q] = v[q];
+  for (int k = 0; k < 16; ++k) {
+    const int owner = 4 * k + (lane >> 4), e = lane & 15;
+    const long o = __shfl(off, owner, 64);
+    const int nn = __shfl(n, owner, 64);
+    const float val = tile[owner * 17 + e];
+    if (e < nn) base[o + e] = val;
   }
 }
 
 __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
+  __shared__ float xch[256 * 17];
   a.t += a.t_base ? *a.t_base : 0u;
   const uint32_t E = a.E, A = a.A, O = a.O, W = A + O;
   const uint32_t nch = max(1u, (O - 2 + 15) / 16);        // bit chunks per raw view (>= 1: chunk 0 also writes id + coordinates)
@@ -81,51 +86,50 @@ __global__ __launch_bounds__(256) void synth_rware_kernel(SynthArgs a) {
   const uint32_t nch_s = a.S > 0 ? max(1u, ((uint32_t)a.S - 2 + 15) / 16) : 0;
   const uint32_t n_state = E * nch_s;                     // (env, chunk) threads of an independent state vector
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid < n_view + n_state) {
-    const bool is_state = gid >= n_view;
+  const int lane = threadIdx.x & 63;
+  float* const tile = xch + (threadIdx.x >> 6) * 64 * 17;
+  const bool is_chunk = gid < n_view + n_state;
+  if (__ballot(is_chunk) != 0) {  // (wave-uniform: the chunk threads of a wave store together)
+    const bool is_state = is_chunk && gid >= n_view;
     const uint32_t i = is_state ? gid - n_view : gid;
     const uint32_t per = is_state ? nch_s : nch;
-    const uint32_t row = i / per, c = i - row * per;      // row = entity (env*A + agent) or env
+    const uint32_t row = is_chunk ? i / per : 0u, c = is_chunk ? i - row * per : 0u;  // row = entity (env*A + agent) or env
     const uint32_t e = is_state ? row : row / A, ag = is_state ? 0u : row - e * A;
     const uint32_t ent = is_state ? (0x80000000u | (a.env_offset + e)) : ((a.env_offset + e) * A + ag);
     const uint32_t nf = is_state ? (uint32_t)a.S : O;     // features of this raw row
     const Philox4 r = philox4x32_10(ent, a.t, c, ENV_STREAM, a.seed_lo, a.seed_hi);
     const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
     const uint32_t f0 = 2 + 16 * c;                       // first feature of the chunk
-    const int n = (int)min(16u, nf - f0);
+    const int n = is_chunk ? (int)min(16u, nf - f0) : 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[lane * 17 + q] = (((wds[q >> 2] >> (8 * (q & 3))) & 0xFFu) < 51u) ? 1.0f : 0.0f;
     float c0 = 0.0f, c1 = 0.0f;
-    if (c == 0) {                                          // the row's grid coordinates (features 0, 1)
+    if (is_chunk && c == 0) {                              // the row's grid coordinates (features 0, 1)
       const Philox4 cm = philox4x32_10(ent, a.t, 0xFFFFu, ENV_STREAM, a.seed_lo, a.seed_hi);
       c0 = (float)(cm.x % 10u);
       c1 = (float)(cm.y % 10u);
     }
-    if (!is_state) {
+    const bool view = is_chunk && !is_state;
+    // agents_view rows
+    wave_store_chunks(a.agents_view, (long)row * W + A + f0, view ? n : 0, tile, lane);
+    if (view && c == 0) {
       float* av = a.agents_view + (long)row * W;
-      store_run(av + A + f0, v, n, ((W & 1u) == 0) && (((A + f0) & 1u) == 0));
-      if (c == 0) {
-        for (uint32_t k2 = 0; k2 < A; ++k2) av[k2] = (k2 == ag) ? 1.0f : 0.0f;
-        av[A] = c0;
-        av[A + 1] = c1;
-      }
-      if (a.S == 0) {                                      // global state = concatenated raw views
-        for (int tile = 0; tile < a.gs_tiles; ++tile) {
-          float* gs = a.global_state + ((long)e * a.gs_tiles + tile) * gsw + (long)ag * O;
-          store_run(gs + f0, v, n, ((gsw & 1u) == 0) && ((O & 1u) == 0));
-          if (c == 0) { gs[0] = c0; gs[1] = c1; }
-        }
-      }
-    } else {
-      for (int tile = 0; tile < a.gs_tiles; ++tile) {
-        float* gs = a.global_state + ((long)e * a.gs_tiles + tile) * gsw;
-        store_run(gs + f0, v, n, (gsw & 1u) == 0);
-        if (c == 0) { gs[0] = c0; gs[1] = c1; }
+      for (uint32_t k2 = 0; k2 < A; ++k2) av[k2] = (k2 == ag) ? 1.0f : 0.0f;
+      av[A] = c0;
+      av[A + 1] = c1;
+    }
+    // global state: the concatenated raw views (S == 0: written by the view threads) or an independent vector (state threads)
+    const bool gs_on = is_chunk && ((a.S == 0) ? !is_state : is_state);
+    for (int t2 = 0; t2 < a.gs_tiles; ++t2) {
+      const long gbase = ((long)e * a.gs_tiles + t2) * gsw + (is_state ? 0L : (long)ag * O);
+      wave_store_chunks(a.global_state, gbase + f0, gs_on ? n : 0, tile, lane);
+      if (gs_on && c == 0) {
+        a.global_state[gbase] = c0;
+        a.global_state[gbase + 1] = c1;
       }
     }
-    return;
   }
+  if (is_chunk) return;
   const uint32_t k = gid - n_view - n_state;
   if (k >= E * A) return;
   const uint32_t e = k / A, ag = k - e * A;
